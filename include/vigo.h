@@ -1,0 +1,256 @@
+/*
+ * vigo.h — C ABI of libvigo_hip.so, the MI355X (gfx950) batched back-end for the
+ * ViGO B-spline optimizer hot path and the min-snap corridor collision checker of
+ * hanyujin02/trajectory_planner.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repo, BT = include/trajectory_planner/bsplineTraj.{h,cpp},
+ * LB = include/trajectory_planner/solver/lbfgs.hpp, BS = .../bspline.cpp,
+ * PO = .../polyTrajOctomap.cpp, PS = .../polyTrajSolver.cpp).
+ *
+ * Conventions
+ *   - plain C types only; no C++/torch types cross this boundary.
+ *   - every array argument is a DEVICE pointer unless the function name ends in
+ *     `_host` (those stage through an internal device workspace).
+ *   - return value: 0 = VIGO_OK, negative = vigo_status_t error.  Per-trajectory solver
+ *     results use the reference's own L-BFGS codes (LB:20-80) in `out_status`.
+ *   - a handle owns its device buffers and HIP stream binding; calls on one handle are
+ *     serialized by the caller; there is no global state.
+ *   - all floating point arrays are fp64 (the reference's arithmetic, BT.h:22) unless the
+ *     name says f32.
+ *
+ * Batch layouts (B trajectories, N control points each, n = 3*(N-6) free scalars):
+ *   ctrl        double[B][N][3]      == B copies of Eigen::MatrixXd(3,N) column-major
+ *                                       (optData::controlPoints, BT.h:22)
+ *   guide_off   int32 [B*N + 1]      CSR offsets: control point (b,i) owns guide pairs
+ *                                       [guide_off[b*N+i], guide_off[b*N+i+1])
+ *                                       (optData::guidePoints[i][j], BT.h:23-24)
+ *   guide_pv    double[G][6]         (p.x p.y p.z v.x v.y v.z) per pair
+ *   guide_unk   uint8 [G]            map_->isUnknown(p) per pair (BT.cpp:841); may be NULL
+ *                                       (=> all known).  vigo_guides_unknown() fills it.
+ *   obs_off     int32 [B + 1]        CSR offsets of dynamic obstacles per trajectory, or NULL
+ *                                       with n_obs_shared obstacles shared by the whole batch
+ *   obs         double[O][9]         (pos.xyz vel.xyz size.xyz)  (BT.h:26-28)
+ *   weights     double[B][4]         (distance, smoothness, feasibility, dynamic) per
+ *                                       trajectory; NULL => the handle's params.  The rebound
+ *                                       loop doubles them per trajectory (BT.cpp:667,672,678).
+ */
+#ifndef VIGO_H
+#define VIGO_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vigo_context* vigo_handle_t;
+
+typedef enum {
+    VIGO_OK = 0,
+    VIGO_ERR_INVALID_ARG = -1,
+    VIGO_ERR_NO_DEVICE = -2,     /* no HIP device / HIP runtime error at create      */
+    VIGO_ERR_HIP = -3,           /* a HIP call failed; see vigo_last_error()          */
+    VIGO_ERR_UNSUPPORTED_N = -4, /* N < 7 or N > VIGO_MAX_CTRL_POINTS                 */
+    VIGO_ERR_NO_GRID = -5,       /* a map query was issued before vigo_set_grid*()    */
+    VIGO_ERR_UNSUPPORTED = -6    /* parameter combination not implemented             */
+} vigo_status_t;
+
+enum { VIGO_MAX_CTRL_POINTS = 64, VIGO_MAX_MEM_SIZE = 16 };
+
+/* arithmetic mode of the solver / cost kernels */
+typedef enum {
+    VIGO_PREC_F64 = 0,       /* fp64 state + reductions (parity-gated default)        */
+    VIGO_PREC_F32 = 1        /* fp32 state, fp64 reductions (throughput mode)         */
+} vigo_precision_t;
+
+/*
+ * Parameters of the hot path.  Field comments give the reference member they mirror.
+ * vigo_default_params() loads cfg/bspline_interactive/bspline_planner_param.yaml values and
+ * the solver settings of BT.cpp:695-699 / LB:942-954.
+ */
+typedef struct {
+    /* cost terms */
+    double dthresh;              /* dthresh_               BT.cpp:35   */
+    double dist_thresh_dynamic;  /* distThreshDynamic_     BT.cpp:143  */
+    double ts_ctrl;              /* controlPointsTs_ = 0.2 BT.h:47     */
+    double ts;                   /* ts_ (bspline_traj/timestep) BT.cpp:26 */
+    double pred_horizon;         /* predHorizon_           BT.cpp:134  */
+    double uncertain_factor;     /* uncertainAwareFactor_  BT.cpp:125  */
+    double w_distance;           /* weightDistance_        BT.cpp:62   */
+    double w_smoothness;         /* weightSmoothness_      BT.cpp:71   */
+    double w_feasibility;        /* weightFeasibility_     BT.cpp:80   */
+    double w_dynamic;            /* weightDynamicObstacle_ BT.cpp:89   */
+    double min_height;           /* minHeight_             BT.cpp:107  */
+    double max_height;           /* maxHeight_             BT.cpp:116  */
+    int32_t plan_in_z;           /* planInZAxis_           BT.cpp:98   */
+    /* L-BFGS (lbfgs_parameter_t, LB:87-191) */
+    int32_t mem_size;            /* BT.cpp:697 (16)  */
+    int32_t max_iterations;      /* BT.cpp:698 (200) */
+    int32_t max_linesearch;      /* LB:948 (40)      */
+    int32_t past;                /* LB:945 (0); only 0 is supported */
+    int32_t reserved_;
+    double g_epsilon;            /* BT.cpp:699 (0.01) */
+    double delta;                /* LB:946 */
+    double min_step;             /* LB:949 */
+    double max_step;             /* LB:950 */
+    double f_dec_coeff;          /* LB:951 ftol */
+    double s_curv_coeff;         /* LB:952 gtol */
+    double xtol;                 /* LB:953 */
+} vigo_params_t;
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+
+/* Replaces: bsplineTraj::bsplineTraj()/init() device-side state (BT.cpp:9-22). */
+int vigo_create(vigo_handle_t* out, int device_ordinal);
+int vigo_destroy(vigo_handle_t h);
+/* Binds all later launches of this handle to a hipStream_t (NULL = default stream). */
+int vigo_set_stream(vigo_handle_t h, void* hip_stream);
+/* Replaces: bsplineTraj::initParam() (BT.cpp:24-172) for the hot-path subset. */
+void vigo_default_params(vigo_params_t* p);
+int vigo_set_params(vigo_handle_t h, const vigo_params_t* p);
+int vigo_get_params(vigo_handle_t h, vigo_params_t* p);
+int vigo_set_precision(vigo_handle_t h, int vigo_precision);
+/* Text of the last HIP/runtime failure on this handle (never NULL). */
+const char* vigo_last_error(vigo_handle_t h);
+/* Library/ABI version, and whether the code object was built for gfx950. */
+int vigo_abi_version(void);
+const char* vigo_build_arch(void);
+
+/* ---- voxel map ------------------------------------------------------------------- */
+
+/*
+ * Dense voxel-map contract standing in for mapManager::occMap (external package
+ * map_manager, un-vendored; call sites BT.h:197,199,312,319,332, BT.cpp:292,412,435,841).
+ *   voxels: uint8[nx][ny][nz] (z fastest), bit0 = inflated-occupied, bit1 = unknown,
+ *           bit2 = occupied (un-inflated; used by the corridor checker's octree semantics).
+ *   index  = floor((p - origin) / res) per axis; outside the box => occupied AND unknown.
+ * The map is SNAPSHOTTED (packed to one bit per voxel per plane in HBM).
+ * Replaces: bsplineTraj::setMap (BT.cpp:187-195), polyTrajOctomap::updateMap (PO.cpp:133-145).
+ */
+int vigo_set_grid(vigo_handle_t h, int nx, int ny, int nz, const double origin[3],
+                  double res, const uint8_t* voxels_dev);
+int vigo_set_grid_host(vigo_handle_t h, int nx, int ny, int nz, const double origin[3],
+                       double res, const uint8_t* voxels_host);
+/* Size in bytes of the packed snapshot for a grid of these dims (3 bit planes). */
+size_t vigo_grid_packed_bytes(int nx, int ny, int nz);
+/* Pack a byte grid into the snapshot format into a caller-owned device buffer (so it can
+ * be broadcast with RCCL), and adopt an already packed snapshot (copy into the handle). */
+int vigo_pack_grid(vigo_handle_t h, int nx, int ny, int nz, const uint8_t* voxels_dev,
+                   uint32_t* packed_dev);
+int vigo_set_grid_packed(vigo_handle_t h, int nx, int ny, int nz, const double origin[3],
+                         double res, const uint32_t* packed_dev);
+/* Metric bounds used by the corridor checker's out-of-bounds test
+ * (octomap getMetricMin/Max, PO.cpp:572-577).  Default: the grid box. */
+int vigo_set_metric_bounds(vigo_handle_t h, const double bmin[3], const double bmax[3]);
+
+/* Point queries, Q points double[Q][3] -> uint8[Q].
+ * which: 0 = isInflatedOccupied, 1 = isUnknown  (BT.cpp:412,841). */
+int vigo_query_points(vigo_handle_t h, int which, int64_t Q, const double* pts,
+                      uint8_t* out);
+/* map_->isUnknown(guidePoint) for every guide pair (loop-invariant per solve, BT.cpp:841). */
+int vigo_guides_unknown(vigo_handle_t h, int64_t G, const double* guide_pv,
+                        uint8_t* out_unk);
+
+/* ---- ViGO cost / gradient --------------------------------------------------------- */
+
+/*
+ * Replaces: bsplineTraj::costFunction (BT.cpp:802-821) = getDistanceCost (:823-932) +
+ * getSmoothnessCost (:934-950) + getFeasibilityCost (:952-999) + getDynamicObstacleCost
+ * (:1001-1064), evaluated for B trajectories in one launch.
+ *   out_cost  double[B]            total weighted cost
+ *   out_grad  double[B][N-6][3]    gradient w.r.t. the free control points (BT.cpp:819)
+ *   out_terms double[B][4] or NULL un-weighted (distance, smoothness, feasibility, dynamic)
+ */
+int vigo_cost_grad(vigo_handle_t h, int B, int N, const double* ctrl,
+                   const int32_t* guide_off, const double* guide_pv, const uint8_t* guide_unk,
+                   const int32_t* obs_off, const double* obs, int n_obs_shared,
+                   const double* weights,
+                   double* out_cost, double* out_grad, double* out_terms);
+
+/*
+ * Replaces: bsplineTraj::optimize (BT.cpp:687-718) -> lbfgs::lbfgs_optimize (LB:1024-1349)
+ * with line_search_morethuente (LB:716-937), for B trajectories in one launch.
+ *   ctrl       in: initial control points; out: optData_.controlPoints as the reference
+ *              leaves them, i.e. the LAST EVALUATED point (BT.cpp:803), not L-BFGS' x.
+ *   out_x      double[B][N-6][3] or NULL: the x vector lbfgs_optimize returns
+ *              (reverted to xp on line-search failure, LB:1192)
+ *   out_status int32[B]  lbfgs_optimize return code (LB:20-80)
+ *   out_fx     double[B] final objective (LB:1328)
+ *   out_iters  int32[B]  iteration counter k at exit;  out_evals int32[B] cost evaluations
+ *   (any out_* except ctrl may be NULL)
+ */
+int vigo_optimize(vigo_handle_t h, int B, int N, double* ctrl,
+                  const int32_t* guide_off, const double* guide_pv, const uint8_t* guide_unk,
+                  const int32_t* obs_off, const double* obs, int n_obs_shared,
+                  const double* weights,
+                  double* out_x, int32_t* out_status, double* out_fx,
+                  int32_t* out_iters, int32_t* out_evals);
+
+/* ---- B-spline evaluation and the rebound-loop gates -------------------------------- */
+
+/*
+ * Replaces: bspline::at (BS.cpp:32-58) on bspline(3, ctrl, ts_ctrl) and its
+ * getDerivative() chains (BS.cpp:64-72).  deriv = 0,1,2.
+ *   times double[T] shared by the batch; out double[B][T][3].
+ */
+int vigo_bspline_eval(vigo_handle_t h, int B, int N, const double* ctrl, int deriv,
+                      int T, const double* times, double* out);
+
+/*
+ * Replaces: bsplineTraj::hasCollisionTrajectory (BT.h:307-325): sample the spline every
+ * dt = res/max_vel/2 and test isInflatedOccupied.
+ *   out_flag uint8[B]; out_first int32[B] index of the first colliding sample or -1.
+ */
+int vigo_traj_collision(vigo_handle_t h, int B, int N, const double* ctrl, double dt,
+                        uint8_t* out_flag, int32_t* out_first);
+/*
+ * Replaces: bsplineTraj::hasDynamicCollisionTrajectory (BT.h:344-368).
+ */
+int vigo_traj_dynamic_collision(vigo_handle_t h, int B, int N, const double* ctrl, double dt,
+                                const int32_t* obs_off, const double* obs, int n_obs_shared,
+                                uint8_t* out_flag);
+/*
+ * Replaces the map queries of bsplineTraj::findCollisionSeg (BT.cpp:403-445):
+ *   out_pt   uint8[B][N]  isInflatedOccupied(ctrl[i])
+ *   out_line uint8[B][N]  isInflatedOccupiedLine(ctrl[i-1], ctrl[i]) (entry 0 = 0)
+ * The segment bookkeeping itself stays on the host (it is a serial scan of these flags).
+ */
+int vigo_ctrl_occupancy(vigo_handle_t h, int B, int N, const double* ctrl,
+                        uint8_t* out_pt, uint8_t* out_line);
+
+/* ---- min-snap corridor collision checker ------------------------------------------- */
+
+/*
+ * Replaces: polyTrajOctomap::checkCollisionTraj (PO.cpp:634-656) -> checkCollision
+ * (:547-568) -> checkCollisionPoint (:571-589), fed by polyTrajSolver::getTrajectory /
+ * getPose (PS.cpp:1125-1137, :1026-1056), for S independent polynomial segments.
+ *   coeffs   double[S][3][deg+1]  x,y,z coefficients in un-normalised local time
+ *   dur      double[S]            segment duration
+ *   n_samp   int32[S]             samples per segment: t_k = k * delT[s], k < n_samp[s]
+ *   delT     double[S]
+ *   box[3], map_res               collision_box / map_resolution (cfg/planner_interactive.yaml)
+ *   out_flag uint8[S]; out_first int32[S] first colliding sample index or -1;
+ *   out_count int32[S] number of colliding samples (may be NULL)
+ */
+int vigo_corridor_check(vigo_handle_t h, int S, int deg, const double* coeffs,
+                        const int32_t* n_samp, const double* delT,
+                        const double box[3], double map_res,
+                        uint8_t* out_flag, int32_t* out_first, int32_t* out_count);
+
+/* The reference's sample clock: t_k of `for (t = 0; ...; t += delT)` (PS.cpp:1129), i.e. the
+ * k-fold floating-point accumulation, evaluated in closed form (host utility, no GPU). */
+double vigo_accumulated_time(double delT, int64_t k);
+
+/* ---- ESDF trilinear query (config 5; no reference counterpart) ------- */
+
+int vigo_set_esdf(vigo_handle_t h, int nx, int ny, int nz, const double origin[3],
+                  double res, const float* dist_dev);
+int vigo_esdf_query(vigo_handle_t h, int64_t Q, const double* pts,
+                    double* out_dist, double* out_grad);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIGO_H */

@@ -1,0 +1,406 @@
+// vigo_api.cpp — the C ABI of libvigo_hip.so (include/vigo.h): handle management, argument
+// checks and kernel launches.  No computation happens on the host: if HIP is unusable every
+// entry point fails loudly (VIGO_ERR_NO_DEVICE / VIGO_ERR_HIP) instead of falling back.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "vigo_exact_time.hpp"
+#include "vigo_internal.hpp"
+
+using vigo::DevConst;
+using vigo::GridView;
+using vigo::SolveArgs;
+
+namespace {
+
+int fail(vigo_handle_t h, int code, const char* what, hipError_t e = hipSuccess) {
+    if (h) {
+        h->last_error = what;
+        if (e != hipSuccess) {
+            h->last_error += ": ";
+            h->last_error += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define VIGO_HIP(h, call)                                                      \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) return fail((h), VIGO_ERR_HIP, #call, e_);       \
+    } while (0)
+
+int ensure_scratch(vigo_handle_t h, size_t bytes) {
+    if (bytes <= h->scratch_bytes) return VIGO_OK;
+    if (h->scratch) (void)hipFree(h->scratch);
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    VIGO_HIP(h, hipMalloc(&h->scratch, want));
+    h->scratch_bytes = want;
+    return VIGO_OK;
+}
+
+int check_solve_args(vigo_handle_t h, int B, int N, const void* ctrl) {
+    if (!h) return VIGO_ERR_INVALID_ARG;
+    if (B < 0 || (B > 0 && !ctrl)) return fail(h, VIGO_ERR_INVALID_ARG, "B < 0 or ctrl == NULL");
+    if (N < 7 || N > VIGO_MAX_CTRL_POINTS) return fail(h, VIGO_ERR_UNSUPPORTED_N, "N outside [7, VIGO_MAX_CTRL_POINTS]");
+    return VIGO_OK;
+}
+
+// accumulated sample times of `for (t = 0; t <= tmax; t += dt)` (BT.h:313, BT.cpp:1442):
+// computed sequentially on the host exactly like the reference so the sample count and every
+// t_k carry the reference's rounding, then uploaded (a few hundred doubles).
+int upload_sample_times(vigo_handle_t h, double tmax, double dt, int* out_T, const double** out_dev) {
+    if (!(dt > 0.0)) return fail(h, VIGO_ERR_INVALID_ARG, "dt must be > 0");
+    std::vector<double> times;
+    for (double t = 0; t <= tmax; t += dt) {
+        times.push_back(t);
+        if (times.size() > (size_t)1 << 24) return fail(h, VIGO_ERR_INVALID_ARG, "too many samples");
+    }
+    int rc = ensure_scratch(h, times.size() * sizeof(double) + 64);
+    if (rc) return rc;
+    if (!times.empty())
+        VIGO_HIP(h, hipMemcpyAsync(h->scratch, times.data(), times.size() * sizeof(double),
+                                   hipMemcpyHostToDevice, h->stream));
+    // the vector dies at return: make sure the copy has consumed it
+    VIGO_HIP(h, hipStreamSynchronize(h->stream));
+    *out_T = (int)times.size();
+    *out_dev = static_cast<const double*>(h->scratch);
+    return VIGO_OK;
+}
+
+void fill_grid_view(vigo_handle_t h, int nx, int ny, int nz, const double origin[3], double res) {
+    GridView& g = h->grid;
+    g.planes = h->grid_planes;
+    g.nx = nx; g.ny = ny; g.nz = nz;
+    g.nzw = (nz + 31) / 32;
+    g.plane_words = (size_t)nx * ny * g.nzw;
+    g.res = res;
+    for (int a = 0; a < 3; ++a) {
+        g.origin[a] = origin[a];
+        g.bmin[a] = origin[a];
+        g.key0[a] = (int)floor(origin[a] / res + 0.5);
+    }
+    g.bmax[0] = origin[0] + nx * res;
+    g.bmax[1] = origin[1] + ny * res;
+    g.bmax[2] = origin[2] + nz * res;
+    h->has_grid = true;
+}
+
+int ensure_grid_storage(vigo_handle_t h, int nx, int ny, int nz) {
+    size_t need = vigo_grid_packed_bytes(nx, ny, nz);
+    if (need > h->grid_capacity_bytes) {
+        if (h->grid_planes) (void)hipFree(h->grid_planes);
+        h->grid_planes = nullptr;
+        h->grid_capacity_bytes = 0;
+        VIGO_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->grid_planes), need));
+        h->grid_capacity_bytes = need;
+    }
+    return VIGO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vigo_abi_version(void) { return 1; }
+double vigo_accumulated_time(double delT, int64_t k) { return vigo::accumulated_time(delT, k); }
+const char* vigo_build_arch(void) { return "gfx950"; }
+
+void vigo_default_params(vigo_params_t* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    // cfg/bspline_interactive/bspline_planner_param.yaml:4-19, BT.h:46-47
+    p->dthresh = 0.5;
+    p->dist_thresh_dynamic = 0.5;
+    p->ts_ctrl = 0.2;
+    p->ts = 0.1;
+    p->pred_horizon = 2.0;
+    p->uncertain_factor = 1.0;
+    p->w_distance = 1.0;
+    p->w_smoothness = 1.0;
+    p->w_feasibility = 1.0;
+    p->w_dynamic = 1.0;
+    p->min_height = 0.7;
+    p->max_height = 1.3;
+    p->plan_in_z = 0;
+    // BT.cpp:695-699 over LB:942-954
+    p->mem_size = 16;
+    p->max_iterations = 200;
+    p->max_linesearch = 40;
+    p->past = 0;
+    p->g_epsilon = 0.01;
+    p->delta = 1e-5;
+    p->min_step = 1e-20;
+    p->max_step = 1e20;
+    p->f_dec_coeff = 1e-4;
+    p->s_curv_coeff = 0.9;
+    p->xtol = 1.0e-16;
+}
+
+int vigo_create(vigo_handle_t* out, int device_ordinal) {
+    if (!out) return VIGO_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return VIGO_ERR_NO_DEVICE;
+    if (device_ordinal < 0 || device_ordinal >= count) return VIGO_ERR_INVALID_ARG;
+    if (hipSetDevice(device_ordinal) != hipSuccess) return VIGO_ERR_NO_DEVICE;
+    vigo_context* h = new vigo_context();
+    h->device = device_ordinal;
+    vigo_default_params(&h->params);
+    h->dc = vigo::make_dev_const(h->params);
+    *out = h;
+    return VIGO_OK;
+}
+
+int vigo_destroy(vigo_handle_t h) {
+    if (!h) return VIGO_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    if (h->grid_planes) (void)hipFree(h->grid_planes);
+    if (h->esdf) (void)hipFree(h->esdf);
+    if (h->scratch) (void)hipFree(h->scratch);
+    delete h;
+    return VIGO_OK;
+}
+
+int vigo_set_stream(vigo_handle_t h, void* hip_stream) {
+    if (!h) return VIGO_ERR_INVALID_ARG;
+    h->stream = static_cast<hipStream_t>(hip_stream);
+    return VIGO_OK;
+}
+
+int vigo_set_params(vigo_handle_t h, const vigo_params_t* p) {
+    if (!h || !p) return VIGO_ERR_INVALID_ARG;
+    if (p->mem_size <= 0 || p->mem_size > VIGO_MAX_MEM_SIZE) return fail(h, VIGO_ERR_UNSUPPORTED, "mem_size outside [1, VIGO_MAX_MEM_SIZE]");
+    if (p->past != 0) return fail(h, VIGO_ERR_UNSUPPORTED, "past != 0 (delta test) is not implemented; the reference runs past = 0");
+    if (!(p->ts > 0) || !(p->ts_ctrl > 0)) return fail(h, VIGO_ERR_INVALID_ARG, "ts and ts_ctrl must be > 0");
+    // the argument checks of lbfgs_optimize (LB:1060-1104): refuse here rather than per trajectory
+    if (p->g_epsilon < 0. || p->delta < 0. || p->min_step < 0. || p->max_step < p->min_step ||
+        p->f_dec_coeff < 0. || p->s_curv_coeff <= p->f_dec_coeff || 1. <= p->s_curv_coeff ||
+        p->xtol < 0. || p->max_linesearch <= 0 || p->max_iterations < 0)
+        return fail(h, VIGO_ERR_INVALID_ARG, "invalid L-BFGS parameter (see lbfgs.hpp:1060-1104)");
+    h->params = *p;
+    h->dc = vigo::make_dev_const(h->params);
+    return VIGO_OK;
+}
+
+int vigo_get_params(vigo_handle_t h, vigo_params_t* p) {
+    if (!h || !p) return VIGO_ERR_INVALID_ARG;
+    *p = h->params;
+    return VIGO_OK;
+}
+
+int vigo_set_precision(vigo_handle_t h, int precision) {
+    if (!h) return VIGO_ERR_INVALID_ARG;
+    if (precision != VIGO_PREC_F64 && precision != VIGO_PREC_F32) return fail(h, VIGO_ERR_INVALID_ARG, "unknown precision");
+    h->precision = precision;
+    return VIGO_OK;
+}
+
+const char* vigo_last_error(vigo_handle_t h) { return h ? h->last_error.c_str() : "null handle"; }
+
+/* ---- voxel map ---------------------------------------------------------------------- */
+
+size_t vigo_grid_packed_bytes(int nx, int ny, int nz) {
+    if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
+    return (size_t)3 * nx * ny * ((nz + 31) / 32) * sizeof(uint32_t);
+}
+
+int vigo_pack_grid(vigo_handle_t h, int nx, int ny, int nz, const uint8_t* voxels_dev, uint32_t* packed_dev) {
+    if (!h || !voxels_dev || !packed_dev || nx <= 0 || ny <= 0 || nz <= 0) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_pack_grid: bad argument");
+    VIGO_HIP(h, (hipError_t)vigo::launch_pack_grid(h->stream, nx, ny, nz, voxels_dev, packed_dev));
+    return VIGO_OK;
+}
+
+int vigo_set_grid(vigo_handle_t h, int nx, int ny, int nz, const double origin[3], double res, const uint8_t* voxels_dev) {
+    if (!h || !voxels_dev || !origin || nx <= 0 || ny <= 0 || nz <= 0 || !(res > 0)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_grid: bad argument");
+    int rc = ensure_grid_storage(h, nx, ny, nz);
+    if (rc) return rc;
+    VIGO_HIP(h, (hipError_t)vigo::launch_pack_grid(h->stream, nx, ny, nz, voxels_dev, h->grid_planes));
+    fill_grid_view(h, nx, ny, nz, origin, res);
+    return VIGO_OK;
+}
+
+int vigo_set_grid_host(vigo_handle_t h, int nx, int ny, int nz, const double origin[3], double res, const uint8_t* voxels_host) {
+    if (!h || !voxels_host || !origin || nx <= 0 || ny <= 0 || nz <= 0 || !(res > 0)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_grid_host: bad argument");
+    size_t bytes = (size_t)nx * ny * nz;
+    int rc = ensure_scratch(h, bytes);
+    if (rc) return rc;
+    VIGO_HIP(h, hipMemcpyAsync(h->scratch, voxels_host, bytes, hipMemcpyHostToDevice, h->stream));
+    rc = vigo_set_grid(h, nx, ny, nz, origin, res, static_cast<const uint8_t*>(h->scratch));
+    if (rc) return rc;
+    VIGO_HIP(h, hipStreamSynchronize(h->stream));
+    return VIGO_OK;
+}
+
+int vigo_set_grid_packed(vigo_handle_t h, int nx, int ny, int nz, const double origin[3], double res, const uint32_t* packed_dev) {
+    if (!h || !packed_dev || !origin || nx <= 0 || ny <= 0 || nz <= 0 || !(res > 0)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_grid_packed: bad argument");
+    int rc = ensure_grid_storage(h, nx, ny, nz);
+    if (rc) return rc;
+    VIGO_HIP(h, hipMemcpyAsync(h->grid_planes, packed_dev, vigo_grid_packed_bytes(nx, ny, nz), hipMemcpyDeviceToDevice, h->stream));
+    fill_grid_view(h, nx, ny, nz, origin, res);
+    return VIGO_OK;
+}
+
+int vigo_set_metric_bounds(vigo_handle_t h, const double bmin[3], const double bmax[3]) {
+    if (!h || !bmin || !bmax) return VIGO_ERR_INVALID_ARG;
+    if (!h->has_grid) return fail(h, VIGO_ERR_NO_GRID, "vigo_set_metric_bounds before vigo_set_grid");
+    for (int a = 0; a < 3; ++a) { h->grid.bmin[a] = bmin[a]; h->grid.bmax[a] = bmax[a]; }
+    return VIGO_OK;
+}
+
+int vigo_query_points(vigo_handle_t h, int which, int64_t Q, const double* pts, uint8_t* out) {
+    if (!h || Q < 0 || (Q > 0 && (!pts || !out)) || which < 0 || which > 1) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_query_points: bad argument");
+    if (!h->has_grid) return fail(h, VIGO_ERR_NO_GRID, "vigo_query_points before vigo_set_grid");
+    VIGO_HIP(h, (hipError_t)vigo::launch_query_points(h->stream, h->grid, which, Q, pts, 3, out));
+    return VIGO_OK;
+}
+
+int vigo_guides_unknown(vigo_handle_t h, int64_t G, const double* guide_pv, uint8_t* out_unk) {
+    if (!h || G < 0 || (G > 0 && (!guide_pv || !out_unk))) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_guides_unknown: bad argument");
+    if (!h->has_grid) return fail(h, VIGO_ERR_NO_GRID, "vigo_guides_unknown before vigo_set_grid");
+    VIGO_HIP(h, (hipError_t)vigo::launch_query_points(h->stream, h->grid, 1, G, guide_pv, 6, out_unk));
+    return VIGO_OK;
+}
+
+/* ---- ViGO cost / gradient / solve ----------------------------------------------------- */
+
+int vigo_cost_grad(vigo_handle_t h, int B, int N, const double* ctrl, const int32_t* guide_off,
+                   const double* guide_pv, const uint8_t* guide_unk, const int32_t* obs_off,
+                   const double* obs, int n_obs_shared, const double* weights, double* out_cost,
+                   double* out_grad, double* out_terms) {
+    int rc = check_solve_args(h, B, N, ctrl);
+    if (rc) return rc;
+    if (n_obs_shared < 0) return fail(h, VIGO_ERR_INVALID_ARG, "n_obs_shared < 0");
+    SolveArgs a{};
+    a.B = B; a.N = N;
+    a.ctrl = const_cast<double*>(ctrl);
+    a.guide_off = guide_off; a.guide_pv = guide_pv; a.guide_unk = guide_unk;
+    a.obs_off = obs_off; a.obs = obs; a.n_obs_shared = n_obs_shared;
+    a.weights = weights;
+    a.out_cost = out_cost; a.out_grad = out_grad; a.out_terms = out_terms;
+    VIGO_HIP(h, (hipError_t)vigo::launch_cost_grad(h->stream, a, h->dc, h->precision));
+    return VIGO_OK;
+}
+
+int vigo_optimize(vigo_handle_t h, int B, int N, double* ctrl, const int32_t* guide_off,
+                  const double* guide_pv, const uint8_t* guide_unk, const int32_t* obs_off,
+                  const double* obs, int n_obs_shared, const double* weights, double* out_x,
+                  int32_t* out_status, double* out_fx, int32_t* out_iters, int32_t* out_evals) {
+    int rc = check_solve_args(h, B, N, ctrl);
+    if (rc) return rc;
+    if (n_obs_shared < 0) return fail(h, VIGO_ERR_INVALID_ARG, "n_obs_shared < 0");
+    SolveArgs a{};
+    a.B = B; a.N = N;
+    a.ctrl = ctrl;
+    a.guide_off = guide_off; a.guide_pv = guide_pv; a.guide_unk = guide_unk;
+    a.obs_off = obs_off; a.obs = obs; a.n_obs_shared = n_obs_shared;
+    a.weights = weights;
+    a.out_x = out_x; a.out_status = out_status; a.out_fx = out_fx;
+    a.out_iters = out_iters; a.out_evals = out_evals;
+    VIGO_HIP(h, (hipError_t)vigo::launch_optimize(h->stream, a, h->dc, h->precision));
+    return VIGO_OK;
+}
+
+/* ---- B-spline evaluation and gates ----------------------------------------------------- */
+
+int vigo_bspline_eval(vigo_handle_t h, int B, int N, const double* ctrl, int deriv, int T,
+                      const double* times, double* out) {
+    if (!h) return VIGO_ERR_INVALID_ARG;
+    if (B < 0 || T < 0 || deriv < 0 || deriv > 2 || ((B > 0 && T > 0) && (!ctrl || !times || !out)))
+        return fail(h, VIGO_ERR_INVALID_ARG, "vigo_bspline_eval: bad argument");
+    if (N < 4 || N > VIGO_MAX_CTRL_POINTS) return fail(h, VIGO_ERR_UNSUPPORTED_N, "N outside [4, VIGO_MAX_CTRL_POINTS]");
+    VIGO_HIP(h, (hipError_t)vigo::launch_bspline_eval(h->stream, B, N, ctrl, h->params.ts_ctrl, deriv, T, times, out));
+    return VIGO_OK;
+}
+
+int vigo_traj_collision(vigo_handle_t h, int B, int N, const double* ctrl, double dt,
+                        uint8_t* out_flag, int32_t* out_first) {
+    if (!h) return VIGO_ERR_INVALID_ARG;
+    if (B < 0 || (B > 0 && (!ctrl || !out_flag))) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_traj_collision: bad argument");
+    if (N < 4 || N > VIGO_MAX_CTRL_POINTS) return fail(h, VIGO_ERR_UNSUPPORTED_N, "N outside [4, VIGO_MAX_CTRL_POINTS]");
+    if (!h->has_grid) return fail(h, VIGO_ERR_NO_GRID, "vigo_traj_collision before vigo_set_grid");
+    int T = 0;
+    const double* times = nullptr;
+    double duration = (N - 3) * h->params.ts_ctrl;  // knots(N), BS.cpp:27
+    int rc = upload_sample_times(h, (1.0 - 0.0) * duration, dt, &T, &times);
+    if (rc) return rc;
+    VIGO_HIP(h, (hipError_t)vigo::launch_traj_collision(h->stream, h->grid, B, N, ctrl, h->params.ts_ctrl, T, times, out_flag, out_first));
+    return VIGO_OK;
+}
+
+int vigo_traj_dynamic_collision(vigo_handle_t h, int B, int N, const double* ctrl, double dt,
+                                const int32_t* obs_off, const double* obs, int n_obs_shared,
+                                uint8_t* out_flag) {
+    if (!h) return VIGO_ERR_INVALID_ARG;
+    if (B < 0 || (B > 0 && (!ctrl || !out_flag)) || n_obs_shared < 0) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_traj_dynamic_collision: bad argument");
+    if (N < 4 || N > VIGO_MAX_CTRL_POINTS) return fail(h, VIGO_ERR_UNSUPPORTED_N, "N outside [4, VIGO_MAX_CTRL_POINTS]");
+    int T = 0;
+    const double* times = nullptr;
+    double duration = (N - 3) * h->params.ts_ctrl;
+    int rc = upload_sample_times(h, duration, dt, &T, &times);
+    if (rc) return rc;
+    VIGO_HIP(h, (hipError_t)vigo::launch_traj_dynamic_collision(h->stream, B, N, ctrl, h->params.ts_ctrl, T, times, obs_off, obs, n_obs_shared, out_flag));
+    return VIGO_OK;
+}
+
+int vigo_ctrl_occupancy(vigo_handle_t h, int B, int N, const double* ctrl, uint8_t* out_pt, uint8_t* out_line) {
+    if (!h) return VIGO_ERR_INVALID_ARG;
+    if (B < 0 || N < 1 || (B > 0 && (!ctrl || !out_pt || !out_line))) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_ctrl_occupancy: bad argument");
+    if (!h->has_grid) return fail(h, VIGO_ERR_NO_GRID, "vigo_ctrl_occupancy before vigo_set_grid");
+    VIGO_HIP(h, (hipError_t)vigo::launch_ctrl_occupancy(h->stream, h->grid, B, N, ctrl, out_pt, out_line));
+    return VIGO_OK;
+}
+
+/* ---- corridor checker ------------------------------------------------------------------- */
+
+int vigo_corridor_check(vigo_handle_t h, int S, int deg, const double* coeffs, const int32_t* n_samp,
+                        const double* delT, const double box[3], double map_res, uint8_t* out_flag,
+                        int32_t* out_first, int32_t* out_count) {
+    if (!h) return VIGO_ERR_INVALID_ARG;
+    if (S < 0 || deg < 0 || deg > 15 || !box || !(map_res > 0) || (S > 0 && (!coeffs || !n_samp || !delT || !out_flag)))
+        return fail(h, VIGO_ERR_INVALID_ARG, "vigo_corridor_check: bad argument");
+    if (!h->has_grid) return fail(h, VIGO_ERR_NO_GRID, "vigo_corridor_check before vigo_set_grid");
+    for (int a = 0; a < 3; ++a) {
+        double q = h->grid.origin[a] / h->grid.res;
+        if (fabs(q - floor(q + 0.5)) > 1e-6)
+            return fail(h, VIGO_ERR_UNSUPPORTED, "corridor checker needs a grid origin that is a multiple of res (octomap keys)");
+    }
+    VIGO_HIP(h, (hipError_t)vigo::launch_corridor_check(h->stream, h->grid, S, deg, coeffs, n_samp, delT, box, map_res,
+                                                        out_flag, out_first, out_count));
+    return VIGO_OK;
+}
+
+/* ---- ESDF ----------------------------------------------------------------------------------- */
+
+int vigo_set_esdf(vigo_handle_t h, int nx, int ny, int nz, const double origin[3], double res, const float* dist_dev) {
+    if (!h || !dist_dev || !origin || nx < 2 || ny < 2 || nz < 2 || !(res > 0)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_esdf: bad argument");
+    size_t bytes = (size_t)nx * ny * nz * sizeof(float);
+    if (bytes > h->esdf_capacity) {
+        if (h->esdf) (void)hipFree(h->esdf);
+        h->esdf = nullptr;
+        h->esdf_capacity = 0;
+        VIGO_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->esdf), bytes));
+        h->esdf_capacity = bytes;
+    }
+    VIGO_HIP(h, hipMemcpyAsync(h->esdf, dist_dev, bytes, hipMemcpyDeviceToDevice, h->stream));
+    h->esdf_view.dist = h->esdf;
+    h->esdf_view.nx = nx; h->esdf_view.ny = ny; h->esdf_view.nz = nz;
+    h->esdf_view.res = res;
+    for (int a = 0; a < 3; ++a) h->esdf_view.origin[a] = origin[a];
+    h->has_esdf = true;
+    return VIGO_OK;
+}
+
+int vigo_esdf_query(vigo_handle_t h, int64_t Q, const double* pts, double* out_dist, double* out_grad) {
+    if (!h || Q < 0 || (Q > 0 && (!pts || !out_dist || !out_grad))) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_esdf_query: bad argument");
+    if (!h->has_esdf) return fail(h, VIGO_ERR_NO_GRID, "vigo_esdf_query before vigo_set_esdf");
+    VIGO_HIP(h, (hipError_t)vigo::launch_esdf_query(h->stream, h->esdf_view, Q, pts, out_dist, out_grad));
+    return VIGO_OK;
+}
+
+}  // extern "C"

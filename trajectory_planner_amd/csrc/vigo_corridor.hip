@@ -1,0 +1,284 @@
+// vigo_corridor.hip — min-snap corridor collision checker (polyTrajOctomap::checkCollisionTraj
+// -> checkCollision -> checkCollisionPoint, PO.cpp:547-589, :634-656) fed by the polynomial
+// sampler (polyTrajSolver::getPose, PS.cpp:1026-1056), plus the trilinear ESDF query.
+//
+// One 256-thread workgroup per polynomial segment:
+//   pass A  every thread walks chunks of 16 consecutive samples (the chunk's first clock value
+//           comes from accumulated_time(), the rest by the reference's own t += delT), and the
+//           block reduces the samples' bounding box;
+//   stage   the voxels that box (+ the collision box + 1 voxel) can touch are copied from the
+//           packed HBM planes into an LDS tile as ONE bit per voxel (unknown | occupied — both
+//           mean "collides" for the sweep, PO.cpp:580-588);
+//   pass B  the samples are re-walked and every lattice point of the box sweep is looked up in
+//           the LDS tile (a segment makes ~10^5 lookups inside a few thousand words).
+// A tile too large for the LDS budget falls back to lookups in the packed planes (L2).
+#include "vigo_exact_time.hpp"
+#include "vigo_grid.hpp"
+
+namespace vigo {
+namespace {
+
+constexpr int kChunk = 16;       // consecutive samples per thread visit
+constexpr int kBlock = 256;
+constexpr int kMaxDeg = 15;
+
+struct CorridorArgs {
+    int S, deg;
+    const double* coeffs;
+    const int32_t* n_samp;
+    const double* delT;
+    double box[3];
+    double map_res;
+    double rf;  // 1.0 / grid.res (octomap resolution_factor)
+    uint8_t* out_flag;
+    int32_t* out_first;
+    int32_t* out_count;
+    int tile_words_cap;
+};
+
+// PS.cpp:1035-1039: x += c[d] * pow(t, d), d ascending (powers by repeated multiplication)
+__device__ __forceinline__ void poly_pos(const double* cf, int deg, double t, double (&p)[3]) {
+    double x = 0, y = 0, z = 0, pw = 1.0;
+    for (int d = 0; d <= deg; ++d) {
+        x += cf[d] * pw;
+        y += cf[(kMaxDeg + 1) + d] * pw;
+        z += cf[2 * (kMaxDeg + 1) + d] * pw;
+        pw *= t;
+    }
+    p[0] = x; p[1] = y; p[2] = z;
+}
+
+// order-preserving float <-> int for LDS atomic min/max
+__device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+struct Tile {
+    int x0, y0, w0;      // first voxel x, y and first z-word covered
+    int tx, ty, tw;      // extent in x, y voxels and z words
+    bool in_lds;
+};
+
+__global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A) {
+    extern __shared__ __align__(16) uint32_t tile_words[];
+    __shared__ double cf[3 * (kMaxDeg + 1)];
+    __shared__ int s_min[3], s_max[3];
+    __shared__ int s_first, s_count;
+
+    const int s = blockIdx.x;
+    if (s >= A.S) return;
+    const int tid = threadIdx.x;
+    const int deg = A.deg;
+    const int n = A.n_samp[s];
+    const double dT = A.delT[s];
+
+    if (tid < 3 * (deg + 1)) {
+        const int ax = tid / (deg + 1), d = tid % (deg + 1);
+        cf[ax * (kMaxDeg + 1) + d] = A.coeffs[((size_t)s * 3 + ax) * (deg + 1) + d];
+    }
+    if (tid < 3) { s_min[tid] = 0x7fffffff; s_max[tid] = (int)0x80000000; }
+    if (tid == 0) { s_first = 0x7fffffff; s_count = 0; }
+    __syncthreads();
+
+    const int n_chunks = (n + kChunk - 1) / kChunk;
+
+    // ---- pass A: bounding box of the (float) sample positions ----
+    {
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (int c = tid; c < n_chunks; c += kBlock) {
+            const int k0 = c * kChunk, k1 = min(n, k0 + kChunk);
+            double t = accumulated_time(dT, k0);
+            for (int k = k0; k < k1; ++k) {
+                double p[3];
+                poly_pos(cf, deg, t, p);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float f = (float)p[a];
+                    lo[a] = fminf(lo[a], f);
+                    hi[a] = fmaxf(hi[a], f);
+                }
+                t += dT;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (lo[a] <= hi[a]) {  // also false for NaN positions (they collide via the bounds test)
+                atomicMin(&s_min[a], f2ord(lo[a]));
+                atomicMax(&s_max[a], f2ord(hi[a]));
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- tile of voxels the sweep can touch (uniform across the block) ----
+    Tile T;
+    {
+        int lo_i[3], hi_i[3];
+        const int dims[3] = {g.nx, g.ny, g.nz};
+        bool any = s_min[0] != 0x7fffffff;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double lo = (double)ord2f(s_min[a]) - A.box[a] / 2;
+            const double hi = (double)ord2f(s_max[a]) + A.box[a] / 2 + A.map_res;
+            double l = floor(A.rf * lo) - g.key0[a] - 1;
+            double h = floor(A.rf * hi) - g.key0[a] + 1;
+            l = fmax(l, 0.0);
+            h = fmin(h, (double)(dims[a] - 1));
+            lo_i[a] = (int)l;
+            hi_i[a] = (int)h;
+            if (!(h >= l)) any = false;
+        }
+        T.x0 = lo_i[0]; T.y0 = lo_i[1]; T.w0 = lo_i[2] >> 5;
+        T.tx = any ? hi_i[0] - lo_i[0] + 1 : 0;
+        T.ty = any ? hi_i[1] - lo_i[1] + 1 : 0;
+        T.tw = any ? (hi_i[2] >> 5) - T.w0 + 1 : 0;
+        const long long words = (long long)T.tx * T.ty * T.tw;
+        T.in_lds = any && words > 0 && words <= A.tile_words_cap;
+        if (T.in_lds) {
+            const uint32_t* unk = g.planes + g.plane_words;
+            const uint32_t* occ = g.planes + 2 * g.plane_words;
+            for (int w = tid; w < (int)words; w += kBlock) {
+                const int lw = w % T.tw;
+                const int ly = (w / T.tw) % T.ty;
+                const int lx = w / (T.tw * T.ty);
+                const size_t gw = ((size_t)(T.x0 + lx) * g.ny + (T.y0 + ly)) * g.nzw + (T.w0 + lw);
+                tile_words[w] = unk[gw] | occ[gw];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- pass B: box sweep per sample ----
+    int my_first = 0x7fffffff, my_count = 0;
+    for (int c = tid; c < n_chunks; c += kBlock) {
+        const int k0 = c * kChunk, k1 = min(n, k0 + kChunk);
+        double t = accumulated_time(dT, k0);
+        for (int k = k0; k < k1; ++k) {
+            double p[3];
+            poly_pos(cf, deg, t, p);
+            const float fx = (float)p[0], fy = (float)p[1], fz = (float)p[2];  // pose2Octomap
+            // PO.cpp:548-555
+            const double xmin = fx - A.box[0] / 2, xmax = fx + A.box[0] / 2;
+            const double ymin = fy - A.box[1] / 2, ymax = fy + A.box[1] / 2;
+            const double zmin = fz - A.box[2] / 2, zmax = fz + A.box[2] / 2;
+            const int xNum = (int)((xmax - xmin) / A.map_res);
+            const int yNum = (int)((ymax - ymin) / A.map_res);
+            const int zNum = (int)((zmax - zmin) / A.map_res);
+            bool hit = false;
+            for (int xi = 0; xi <= xNum && !hit; ++xi) {
+                const float qx = (float)(xmin + xi * A.map_res);
+                const bool x_out = (qx < g.bmin[0]) || (qx > g.bmax[0]);
+                const int kx = (int)floor(A.rf * (double)qx) - g.key0[0];
+                for (int yi = 0; yi <= yNum && !hit; ++yi) {
+                    const float qy = (float)(ymin + yi * A.map_res);
+                    const bool y_out = (qy < g.bmin[1]) || (qy > g.bmax[1]);
+                    const int ky = (int)floor(A.rf * (double)qy) - g.key0[1];
+                    for (int zi = 0; zi <= zNum; ++zi) {
+                        const float qz = (float)(zmin + zi * A.map_res);
+                        // PO.cpp:572-577 metric bounds, then OcTree::search == NULL -> occupied
+                        if (x_out || y_out || (qz < g.bmin[2]) || (qz > g.bmax[2])) { hit = true; break; }
+                        const int kz = (int)floor(A.rf * (double)qz) - g.key0[2];
+                        if (kx < 0 || ky < 0 || kz < 0 || kx >= g.nx || ky >= g.ny || kz >= g.nz) { hit = true; break; }
+                        unsigned bit;
+                        const int lx = kx - T.x0, ly = ky - T.y0, lw = (kz >> 5) - T.w0;
+                        if (T.in_lds && lx >= 0 && ly >= 0 && lw >= 0 && lx < T.tx && ly < T.ty && lw < T.tw) {
+                            bit = (tile_words[(lx * T.ty + ly) * T.tw + lw] >> (kz & 31)) & 1u;
+                        } else {
+                            bit = (grid_bits_at(g, kx, ky, kz) >> 1) != 0;  // unknown | occupied
+                        }
+                        if (bit) { hit = true; break; }
+                    }
+                }
+            }
+            if (hit) {
+                if (k < my_first) my_first = k;
+                ++my_count;
+            }
+            t += dT;
+        }
+    }
+    if (my_count) {
+        atomicMin(&s_first, my_first);
+        atomicAdd(&s_count, my_count);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        A.out_flag[s] = (uint8_t)(s_count > 0);
+        if (A.out_first) A.out_first[s] = s_count > 0 ? s_first : -1;
+        if (A.out_count) A.out_count[s] = s_count;
+    }
+}
+
+// ---- trilinear ESDF (own definition, see oracle/vigo_oracle.c vgo_esdf_query) ------------
+__global__ void k_esdf_query(EsdfView E, int64_t Q, const double* __restrict__ pts,
+                             double* __restrict__ out_d, double* __restrict__ out_g) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const int n[3] = {E.nx, E.ny, E.nz};
+    int i0[3];
+    double f[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double u = (pts[q * 3 + a] - E.origin[a]) / E.res - 0.5;
+        const double fl = floor(u);
+        int i = (int)fl;
+        double fr = u - fl;
+        if (i < 0) { i = 0; fr = 0.0; }
+        if (i > n[a] - 2) { i = n[a] - 2; fr = 1.0; }
+        i0[a] = i;
+        f[a] = fr;
+    }
+    double v[2][2][2];
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const float* row = E.dist + ((size_t)(i0[0] + dx) * E.ny + (i0[1] + dy)) * E.nz + i0[2];
+            v[dx][dy][0] = (double)row[0];
+            v[dx][dy][1] = (double)row[1];
+        }
+    const double c00 = v[0][0][0] * (1 - f[0]) + v[1][0][0] * f[0];
+    const double c01 = v[0][0][1] * (1 - f[0]) + v[1][0][1] * f[0];
+    const double c10 = v[0][1][0] * (1 - f[0]) + v[1][1][0] * f[0];
+    const double c11 = v[0][1][1] * (1 - f[0]) + v[1][1][1] * f[0];
+    const double c0 = c00 * (1 - f[1]) + c10 * f[1];
+    const double c1 = c01 * (1 - f[1]) + c11 * f[1];
+    out_d[q] = c0 * (1 - f[2]) + c1 * f[2];
+    const double gx00 = v[1][0][0] - v[0][0][0], gx01 = v[1][0][1] - v[0][0][1];
+    const double gx10 = v[1][1][0] - v[0][1][0], gx11 = v[1][1][1] - v[0][1][1];
+    const double gx0 = gx00 * (1 - f[1]) + gx10 * f[1];
+    const double gx1 = gx01 * (1 - f[1]) + gx11 * f[1];
+    out_g[q * 3 + 0] = (gx0 * (1 - f[2]) + gx1 * f[2]) / E.res;
+    const double gy0 = c10 - c00, gy1 = c11 - c01;
+    out_g[q * 3 + 1] = (gy0 * (1 - f[2]) + gy1 * f[2]) / E.res;
+    out_g[q * 3 + 2] = (c1 - c0) / E.res;
+}
+
+}  // namespace
+
+int launch_corridor_check(hipStream_t s, const GridView& g, int S, int deg, const double* coeffs,
+                          const int32_t* n_samp, const double* delT, const double box[3],
+                          double map_res, uint8_t* out_flag, int32_t* out_first, int32_t* out_count) {
+    if (S <= 0) return hipSuccess;
+    CorridorArgs A{};
+    A.S = S; A.deg = deg;
+    A.coeffs = coeffs; A.n_samp = n_samp; A.delT = delT;
+    A.box[0] = box[0]; A.box[1] = box[1]; A.box[2] = box[2];
+    A.map_res = map_res;
+    A.rf = 1.0 / g.res;
+    A.out_flag = out_flag; A.out_first = out_first; A.out_count = out_count;
+    const int tile_bytes = 32 * 1024;
+    A.tile_words_cap = tile_bytes / 4;
+    hipLaunchKernelGGL(k_corridor, dim3(S), dim3(kBlock), tile_bytes, s, g, A);
+    return (int)hipGetLastError();
+}
+
+int launch_esdf_query(hipStream_t s, const EsdfView& e, int64_t Q, const double* pts,
+                      double* out_dist, double* out_grad) {
+    if (Q <= 0) return hipSuccess;
+    const int block = 256;
+    hipLaunchKernelGGL(k_esdf_query, dim3((unsigned)((Q + block - 1) / block)), dim3(block), 0, s, e, Q, pts,
+                       out_dist, out_grad);
+    return (int)hipGetLastError();
+}
+
+}  // namespace vigo

@@ -1,0 +1,122 @@
+// vigo_internal.hpp — host-side types shared by the C-ABI layer and the kernel launchers.
+// Not part of the public boundary (that is include/vigo.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/vigo.h"
+
+namespace vigo {
+
+// Scalars derived from vigo_params_t once on the host, with the reference's own expressions
+// (BT.cpp:835, :959, :1007-1009) so the device sees the same bits as the CPU path.
+struct DevConst {
+    // distance term (BT.cpp:835)
+    double dth, da, db, dc;
+    double unc_factor;
+    // height band (BT.cpp:836-837, plan_in_z only)
+    double hth, ha, hb, hc, min_h, max_h;
+    // feasibility (BT.cpp:955-959)
+    double ts_ctrl, ts_inv_sqr;
+    // dynamic obstacles (BT.cpp:1007-1009)
+    double ts, thr_dyn, oa, ob, oc;
+    int pred_num;
+    int plan_in_z;
+    // default weights
+    double w[4];
+    // L-BFGS (LB:87-191)
+    int mem_size, max_iterations, max_linesearch;
+    double g_epsilon, min_step, max_step, ftol, gtol, xtol;
+};
+
+DevConst make_dev_const(const vigo_params_t& P);
+
+struct SolveArgs {
+    int B, N;
+    double* ctrl;  // in/out for optimize, read-only for cost_grad
+    const int32_t* guide_off;
+    const double* guide_pv;
+    const uint8_t* guide_unk;
+    const int32_t* obs_off;
+    const double* obs;
+    int n_obs_shared;
+    const double* weights;
+    // optimize outputs
+    double* out_x;
+    int32_t* out_status;
+    double* out_fx;
+    int32_t* out_iters;
+    int32_t* out_evals;
+    // cost_grad outputs
+    double* out_cost;
+    double* out_grad;
+    double* out_terms;
+};
+
+// Packed voxel snapshot in HBM: three bit planes (inflated-occupied, unknown, occupied), each
+// nx*ny rows of nzw 32-bit words, z fastest (bit k of word w = voxel z = 32*w + k).
+struct GridView {
+    const uint32_t* planes;  // 3 * plane_words
+    size_t plane_words;
+    int nx, ny, nz, nzw;
+    double origin[3];
+    double res;
+    double bmin[3], bmax[3];
+    int key0[3];  // octomap key of voxel index 0 minus 32768 (corridor checker)
+};
+
+struct EsdfView {
+    const float* dist;
+    int nx, ny, nz;
+    double origin[3];
+    double res;
+};
+
+// launchers (each returns hipError_t as int)
+int launch_cost_grad(hipStream_t s, const SolveArgs& a, const DevConst& k, int precision);
+int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, int precision);
+
+int launch_pack_grid(hipStream_t s, int nx, int ny, int nz, const uint8_t* vox, uint32_t* packed);
+int launch_query_points(hipStream_t s, const GridView& g, int which, int64_t Q, const double* pts,
+                        int pt_stride, uint8_t* out);
+int launch_bspline_eval(hipStream_t s, int B, int N, const double* ctrl, double ts_ctrl, int deriv,
+                        int T, const double* times, double* out);
+int launch_traj_collision(hipStream_t s, const GridView& g, int B, int N, const double* ctrl,
+                          double ts_ctrl, int T, const double* times, uint8_t* out_flag,
+                          int32_t* out_first);
+int launch_traj_dynamic_collision(hipStream_t s, int B, int N, const double* ctrl, double ts_ctrl,
+                                  int T, const double* times, const int32_t* obs_off,
+                                  const double* obs, int n_obs_shared, uint8_t* out_flag);
+int launch_ctrl_occupancy(hipStream_t s, const GridView& g, int B, int N, const double* ctrl,
+                          uint8_t* out_pt, uint8_t* out_line);
+int launch_corridor_check(hipStream_t s, const GridView& g, int S, int deg, const double* coeffs,
+                          const int32_t* n_samp, const double* delT, const double box[3],
+                          double map_res, uint8_t* out_flag, int32_t* out_first, int32_t* out_count);
+int launch_esdf_query(hipStream_t s, const EsdfView& e, int64_t Q, const double* pts,
+                      double* out_dist, double* out_grad);
+
+}  // namespace vigo
+
+struct vigo_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    vigo_params_t params;
+    vigo::DevConst dc;
+    int precision = VIGO_PREC_F64;
+    std::string last_error;
+    // voxel snapshot
+    uint32_t* grid_planes = nullptr;
+    size_t grid_capacity_bytes = 0;
+    vigo::GridView grid{};
+    bool has_grid = false;
+    // esdf
+    float* esdf = nullptr;
+    size_t esdf_capacity = 0;
+    vigo::EsdfView esdf_view{};
+    bool has_esdf = false;
+    // scratch (sample-time tables, corridor checkpoints, staging of *_host calls)
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+};

@@ -1,0 +1,203 @@
+// vigo_map.hip — voxel snapshot packing, point queries, B-spline evaluation and the
+// rebound-loop gates (hasCollisionTrajectory, hasDynamicCollisionTrajectory, the map queries
+// of findCollisionSeg).  All HBM-bound byte/bit work: coalesced reads, one bit per voxel per
+// plane so a 256^3 plane is 2 MiB (L2-resident per XCD) and a 512^3 plane 16 MiB (MALL).
+//
+// These gates look each sample up directly in the packed planes (L2 hits): a trajectory makes
+// ~120-240 lookups scattered over a 7 m path, fewer words than staging its bounding volume in
+// LDS would read.  The LDS-tiled path is the corridor checker (vigo_corridor.hip), where one
+// segment makes ~10^5 lookups inside a small volume.
+#include "vigo_grid.hpp"
+
+namespace vigo {
+namespace {
+
+// one thread per output word triple: reads 32 voxels along z, writes one word per plane
+__global__ void k_pack_grid(int nx, int ny, int nz, int nzw, const uint8_t* __restrict__ vox,
+                            uint32_t* __restrict__ packed) {
+    const size_t plane_words = (size_t)nx * ny * nzw;
+    const size_t wi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= plane_words) return;
+    const size_t col = wi / nzw;
+    const int w = (int)(wi % nzw);
+    const uint8_t* src = vox + col * nz + (size_t)w * 32;
+    const int cnt = min(32, nz - w * 32);
+    uint32_t b0 = 0, b1 = 0, b2 = 0;
+    if (cnt == 32 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4 q[2] = {s4[0], s4[1]};
+        const uint32_t* wds = reinterpret_cast<const uint32_t*>(q);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t v = (wds[i] >> (8 * j)) & 0xFFu;
+                const int bit = 4 * i + j;
+                b0 |= (v & 1u) << bit;
+                b1 |= ((v >> 1) & 1u) << bit;
+                b2 |= ((v >> 2) & 1u) << bit;
+            }
+        }
+    } else {
+        for (int i = 0; i < cnt; ++i) {
+            const uint32_t v = src[i];
+            b0 |= (v & 1u) << i;
+            b1 |= ((v >> 1) & 1u) << i;
+            b2 |= ((v >> 2) & 1u) << i;
+        }
+    }
+    packed[wi] = b0;
+    packed[plane_words + wi] = b1;
+    packed[2 * plane_words + wi] = b2;
+}
+
+__global__ void k_query_points(GridView g, int plane, int64_t Q, const double* __restrict__ pts,
+                               int stride, uint8_t* __restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const double* p = pts + q * stride;
+    out[q] = (uint8_t)grid_plane_pos(g, plane, p[0], p[1], p[2]);
+}
+
+// grid: (ceil(T/256), B)
+__global__ void k_bspline_eval(int B, int N, const double* __restrict__ ctrl, double ts, int deriv,
+                               int T, const double* __restrict__ times, double* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= T) return;
+    double p[3];
+    traj_eval(ctrl + (size_t)b * N * 3, N, ts, deriv, times[k], p);
+    double* dst = out + ((size_t)b * T + k) * 3;
+    dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
+}
+
+// one 64-lane wave per trajectory; lanes stride over the samples; first hit = wave min
+__global__ void __launch_bounds__(64) k_traj_collision(GridView g, int B, int N, const double* __restrict__ ctrl,
+                                                       double ts, int T, const double* __restrict__ times,
+                                                       uint8_t* __restrict__ out_flag, int32_t* __restrict__ out_first) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const double* c = ctrl + (size_t)b * N * 3;
+    int first = 0x7fffffff;
+    for (int k = threadIdx.x; k < T; k += 64) {
+        double p[3];
+        traj_eval(c, N, ts, 0, times[k], p);
+        if (grid_plane_pos(g, 0, p[0], p[1], p[2])) { first = k; break; }  // k ascends per lane
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) first = min(first, __shfl_xor(first, m, 64));
+    if (threadIdx.x == 0) {
+        out_flag[b] = first != 0x7fffffff;
+        if (out_first) out_first[b] = first != 0x7fffffff ? first : -1;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_traj_dynamic_collision(int B, int N, const double* __restrict__ ctrl, double ts,
+                                                               int T, const double* __restrict__ times,
+                                                               const int32_t* __restrict__ obs_off,
+                                                               const double* __restrict__ obs, int n_obs_shared,
+                                                               uint8_t* __restrict__ out_flag) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const double* c = ctrl + (size_t)b * N * 3;
+    const int o0 = obs_off ? obs_off[b] : 0;
+    const int o1 = obs_off ? obs_off[b + 1] : (obs ? n_obs_shared : 0);
+    int hit = 0;
+    for (int k = threadIdx.x; k < T && !hit; k += 64) {
+        double p[3];
+        traj_eval(c, N, ts, 0, times[k], p);
+        for (int j = o0; j < o1; ++j) {
+            const double* o = obs + 9 * (size_t)j;
+            const double size = fmin(o[6] / 2, o[7] / 2);  // BT.h:358 (min, unlike the cost term)
+            const double dx = p[0] - o[0], dy = p[1] - o[1];
+            const double dist = sqrt((dx * dx + dy * dy) + 0.0) - size;
+            if (dist < 0) { hit = 1; break; }
+        }
+    }
+    hit = __any(hit);
+    if (threadIdx.x == 0) out_flag[b] = (uint8_t)(hit != 0);
+}
+
+// one thread per control point: point flag and the line (i-1, i) flag
+__global__ void k_ctrl_occupancy(GridView g, int B, int N, const double* __restrict__ ctrl,
+                                 uint8_t* __restrict__ out_pt, uint8_t* __restrict__ out_line) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * N) return;
+    const int i = (int)(idx % N);
+    const double* p = ctrl + idx * 3;
+    const unsigned occ = grid_plane_pos(g, 0, p[0], p[1], p[2]);
+    out_pt[idx] = (uint8_t)occ;
+    unsigned line = 0;
+    if (i > 0) {
+        const double* q = p - 3;  // previous control point
+        line = grid_plane_pos(g, 0, q[0], q[1], q[2]) | occ;
+        if (!line) {
+            const double d0 = p[0] - q[0], d1 = p[1] - q[1], d2 = p[2] - q[2];
+            const double dist = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
+            const double i0 = d0 / dist * g.res, i1 = d1 / dist * g.res, i2 = d2 / dist * g.res;
+            const int steps = (int)(dist / g.res);
+            for (int s = 1; s < steps; ++s) {
+                if (grid_plane_pos(g, 0, q[0] + s * i0, q[1] + s * i1, q[2] + s * i2)) { line = 1; break; }
+            }
+        }
+    }
+    out_line[idx] = (uint8_t)line;
+}
+
+}  // namespace
+
+int launch_pack_grid(hipStream_t s, int nx, int ny, int nz, const uint8_t* vox, uint32_t* packed) {
+    const int nzw = (nz + 31) / 32;
+    const size_t words = (size_t)nx * ny * nzw;
+    const int block = 256;
+    const size_t grid = (words + block - 1) / block;
+    hipLaunchKernelGGL(k_pack_grid, dim3((unsigned)grid), dim3(block), 0, s, nx, ny, nz, nzw, vox, packed);
+    return (int)hipGetLastError();
+}
+
+int launch_query_points(hipStream_t s, const GridView& g, int which, int64_t Q, const double* pts,
+                        int pt_stride, uint8_t* out) {
+    if (Q <= 0) return hipSuccess;
+    const int block = 256;
+    hipLaunchKernelGGL(k_query_points, dim3((unsigned)((Q + block - 1) / block)), dim3(block), 0, s, g, which, Q, pts,
+                       pt_stride, out);
+    return (int)hipGetLastError();
+}
+
+int launch_bspline_eval(hipStream_t s, int B, int N, const double* ctrl, double ts_ctrl, int deriv,
+                        int T, const double* times, double* out) {
+    if (B <= 0 || T <= 0) return hipSuccess;
+    const int block = 64;
+    hipLaunchKernelGGL(k_bspline_eval, dim3((T + block - 1) / block, B), dim3(block), 0, s, B, N, ctrl, ts_ctrl,
+                       deriv, T, times, out);
+    return (int)hipGetLastError();
+}
+
+int launch_traj_collision(hipStream_t s, const GridView& g, int B, int N, const double* ctrl,
+                          double ts_ctrl, int T, const double* times, uint8_t* out_flag,
+                          int32_t* out_first) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_traj_collision, dim3(B), dim3(64), 0, s, g, B, N, ctrl, ts_ctrl, T, times, out_flag, out_first);
+    return (int)hipGetLastError();
+}
+
+int launch_traj_dynamic_collision(hipStream_t s, int B, int N, const double* ctrl, double ts_ctrl,
+                                  int T, const double* times, const int32_t* obs_off,
+                                  const double* obs, int n_obs_shared, uint8_t* out_flag) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_traj_dynamic_collision, dim3(B), dim3(64), 0, s, B, N, ctrl, ts_ctrl, T, times, obs_off, obs,
+                       n_obs_shared, out_flag);
+    return (int)hipGetLastError();
+}
+
+int launch_ctrl_occupancy(hipStream_t s, const GridView& g, int B, int N, const double* ctrl,
+                          uint8_t* out_pt, uint8_t* out_line) {
+    const int64_t total = (int64_t)B * N;
+    if (total <= 0) return hipSuccess;
+    const int block = 256;
+    hipLaunchKernelGGL(k_ctrl_occupancy, dim3((unsigned)((total + block - 1) / block)), dim3(block), 0, s, g, B, N,
+                       ctrl, out_pt, out_line);
+    return (int)hipGetLastError();
+}
+
+}  // namespace vigo
