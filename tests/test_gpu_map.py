@@ -1,0 +1,158 @@
+"""-m gpu: voxel snapshot, point queries, B-spline evaluation, the rebound-loop gates, the
+corridor checker and the ESDF sampler against the CPU oracle (bit-exact for flags/indices and
+for the fp64 spline values; ESDF to 1e-12)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as ol
+from gpu_util import to_dev
+from trajectory_planner_amd import synth
+from trajectory_planner_amd.vigo import Vigo, default_params
+
+pytestmark = pytest.mark.gpu
+
+
+def set_world(v, world):
+    v.set_grid(to_dev(world.voxels, v.device), world.origin, world.res)
+
+
+def test_point_queries_and_packing(vigo_handle, small_world):
+    v = vigo_handle
+    set_world(v, small_world)
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-7, 7, size=(20000, 3))
+    pts[:100] = small_world.origin + rng.integers(0, 128, size=(100, 3)) * small_world.res   # on voxel faces
+    for which in (0, 1):
+        out = v.query_points(to_dev(pts, v.device), which).cpu().numpy()
+        assert np.array_equal(out, synth.lookup(small_world, pts, which))
+    # non-multiple-of-32 z extent and odd dims go through the tail path of the packer
+    w2 = synth.World(np.ascontiguousarray(small_world.voxels[:77, :45, :41]), small_world.origin, 0.1, small_world.boxes)
+    set_world(v, w2)
+    out = v.query_points(to_dev(pts, v.device), 0).cpu().numpy()
+    assert np.array_equal(out, synth.lookup(w2, pts, 0))
+    # packed snapshot round trip (the RCCL broadcast path)
+    packed = v.pack_grid(to_dev(small_world.voxels, v.device))
+    v2 = Vigo(0)
+    v2.set_grid_packed(packed, small_world.voxels.shape, small_world.origin, small_world.res)
+    assert np.array_equal(v2.query_points(to_dev(pts, v.device), 1).cpu().numpy(), synth.lookup(small_world, pts, 1))
+    g = v2.guides_unknown(to_dev(np.concatenate([pts, pts], axis=1), v.device)).cpu().numpy()
+    assert np.array_equal(g, synth.lookup(small_world, pts, 1))
+    v2.close()
+
+
+def test_bspline_eval_is_bit_exact(vigo_handle, small_world):
+    v = vigo_handle
+    b = synth.make_bspline_batch(small_world, 17, 32, 3, start_range=3.0)
+    P = default_params()
+    dur = (b.N - 3) * P.ts_ctrl
+    n = ol.oracle().vgo_sample_times(dur, 0.05, None, 0)
+    times = np.zeros(n)
+    ol.oracle().vgo_sample_times(dur, 0.05, ol._d(times), n)
+    times = np.concatenate([times, [-0.3, dur, dur + 1.0, 0.2, 0.4]])   # clamps and exact knots
+    for deriv in (0, 1, 2):
+        out = v.bspline_eval(to_dev(b.ctrl, v.device), to_dev(times, v.device), deriv).cpu().numpy()
+        ref = np.zeros_like(out)
+        for i in range(b.B):
+            c = np.ascontiguousarray(b.ctrl[i])
+            for k, t in enumerate(times):
+                ol.oracle().vgo_traj_eval(b.N, ol._d(c), P.ts_ctrl, deriv, float(t), ol._d(ref[i, k]))
+        assert np.array_equal(out, ref), deriv
+
+
+def test_gates_match_oracle(vigo_handle, small_world):
+    v = vigo_handle
+    set_world(v, small_world)
+    g, keep = ol.make_grid(small_world)
+    O = ol.oracle()
+    P = default_params()
+    for N, dt in ((32, 0.05), (20, 0.025), (64, 0.05)):
+        b = synth.make_bspline_batch(small_world, 300, N, 8 + N, start_range=4.0, n_obs=2)
+        ctrl = to_dev(b.ctrl, v.device)
+        flag, first = v.traj_collision(ctrl, dt)
+        pt, line = v.ctrl_occupancy(ctrl)
+        dyn = v.traj_dynamic_collision(ctrl, dt, to_dev(b.obs_off, v.device), to_dev(b.obs, v.device))
+        flag, first, pt, line, dyn = (t.cpu().numpy() for t in (flag, first, pt, line, dyn))
+        for i in range(b.B):
+            c = np.ascontiguousarray(b.ctrl[i])
+            fi = C.c_int()
+            f = O.vgo_traj_collision(C.byref(g), N, ol._d(c), P.ts_ctrl, dt, C.byref(fi))
+            assert f == flag[i] and fi.value == first[i], (i, f, flag[i], fi.value, first[i])
+            p_ref, l_ref = np.zeros(N, dtype=np.uint8), np.zeros(N, dtype=np.uint8)
+            O.vgo_ctrl_occupancy(C.byref(g), N, ol._d(c), ol._u(p_ref), ol._u(l_ref))
+            assert np.array_equal(p_ref, pt[i]) and np.array_equal(l_ref, line[i])
+            o = np.ascontiguousarray(b.obs[b.obs_off[i]:b.obs_off[i + 1]])
+            assert O.vgo_traj_dynamic_collision(N, ol._d(c), P.ts_ctrl, dt, len(o), ol._d(o)) == dyn[i]
+        if N <= 20:   # longer paths leave this 12.8 m world (out of map counts as occupied)
+            assert 0 < flag.mean() < 1
+        assert line.any()
+
+
+def maze_like_world(n=96, res=0.1, seed=5):
+    """occupied / free / unknown voxels with an origin on the octomap key lattice"""
+    rng = np.random.default_rng(seed)
+    vox = np.zeros((n, n, 40), dtype=np.uint8)
+    for _ in range(40):
+        c = rng.integers(5, n - 5, size=2)
+        s = rng.integers(1, 5, size=2)
+        vox[c[0] - s[0]:c[0] + s[0], c[1] - s[1]:c[1] + s[1], 0:rng.integers(10, 40)] |= 4
+    unk = rng.random((n // 8, n // 8, 5)) < 0.08
+    vox[np.repeat(np.repeat(np.repeat(unk, 8, 0), 8, 1), 8, 2)] |= 2
+    return synth.World(vox, np.array([-4.8, -4.8, -0.5]), res, np.zeros((0, 6)))
+
+
+def test_corridor_checker_matches_oracle(vigo_handle):
+    v = vigo_handle
+    w = maze_like_world()
+    set_world(v, w)
+    g, keep = ol.make_grid(w)
+    O = ol.oracle()
+    box = np.array([0.4, 0.4, 0.2])
+    coeffs, n_samp, delT, dur = synth.make_corridor_segments(11, 96, extent_lo=(-4, -4, 0.6), extent_hi=(4, 4, 1.6), n_samples=3000)
+    n_samp[:8] = [0, 1, 2, 15, 16, 17, 255, 4097]          # ragged sample counts
+    delT[8:16] = 0.1                                       # the reference's sample_delta_time
+    n_samp[8:16] = (dur[8:16] / 0.1).astype(np.int32) + 1
+    coeffs[16, :, 0] = [4.6, 0.0, 1.0]                     # leaves the metric bounds
+    coeffs[17, 0, 1] = 3.0                                 # long fast segment: tile too big for LDS
+    coeffs[17, 1, 1] = 2.5
+    for map_res in (0.2, 0.1):
+        flag, first, count = v.corridor_check(to_dev(coeffs, v.device), to_dev(n_samp, v.device), to_dev(delT, v.device), box, map_res)
+        flag, first, count = flag.cpu().numpy(), first.cpu().numpy(), count.cpu().numpy()
+        for s in range(len(coeffs)):
+            fi, cn = C.c_int(), C.c_int()
+            c = np.ascontiguousarray(coeffs[s])
+            f = O.vgo_corridor_check_segment(C.byref(g), 7, ol._d(c), int(n_samp[s]), float(delT[s]), ol._d(box), map_res,
+                                             C.byref(fi), C.byref(cn))
+            assert (f, fi.value, cn.value) == (flag[s], first[s], count[s]), (s, map_res, f, fi.value, cn.value, flag[s], first[s], count[s])
+        assert 0 < flag.mean() < 1
+    # tighter metric bounds make everything near the rim collide (octomap getMetricMin/Max)
+    v.set_metric_bounds([-1, -1, 0.0], [1, 1, 3.0])
+    flag2, _, _ = v.corridor_check(to_dev(coeffs, v.device), to_dev(n_samp, v.device), to_dev(delT, v.device), box, 0.2)
+    g.bmin[:] = [-1, -1, 0.0]
+    g.bmax[:] = [1, 1, 3.0]
+    for s in range(len(coeffs)):
+        c = np.ascontiguousarray(coeffs[s])
+        f = O.vgo_corridor_check_segment(C.byref(g), 7, ol._d(c), int(n_samp[s]), float(delT[s]), ol._d(box), 0.2, None, None)
+        assert f == flag2.cpu().numpy()[s]
+
+
+def test_esdf_query_matches_oracle_and_sphere(vigo_handle):
+    v = vigo_handle
+    n, res = 64, 0.1
+    dist, origin = synth.sphere_esdf(n, res, (0.3, -0.2, 0.1), 1.0)
+    v.set_esdf(to_dev(dist, v.device), origin, res)
+    rng = np.random.default_rng(2)
+    pts = rng.uniform(-3.6, 3.6, size=(5000, 3))       # includes points outside the lattice (clamped)
+    d, g = v.esdf_query(to_dev(pts, v.device))
+    d, g = d.cpu().numpy(), g.cpu().numpy()
+    for i in range(0, 5000, 7):
+        dd, gg = C.c_double(), np.zeros(3)
+        ol.oracle().vgo_esdf_query(n, n, n, ol._d(origin), res, dist.ctypes.data_as(C.POINTER(C.c_float)), ol._d(pts[i]),
+                                   C.byref(dd), ol._d(gg))
+        assert d[i] == dd.value and np.array_equal(g[i], gg)
+    inside = np.abs(pts).max(1) < 3.0
+    r = pts - np.array([0.3, -0.2, 0.1])
+    far = inside & (np.linalg.norm(r, axis=1) > 0.3)
+    assert np.max(np.abs(d[far] - (np.linalg.norm(r[far], axis=1) - 1.0))) < 1e-2
