@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py — B-spline trajectories/s of the batched ViGO solve on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch that is already resident in HBM:
+restore the initial control points (D2D), look up isUnknown for every guide point in the voxel
+snapshot (bsplineTraj.cpp:841, hoisted), and run the whole 50-iteration L-BFGS solve for all
+trajectories in ONE kernel launch (vigo_optimize).  N > 1: every rank owns an independent batch
+of the same size (weak scaling); the only collective is the one-off RCCL broadcast of the packed
+voxel snapshot from rank 0 before the timed region (reported as map_bcast_ms).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     achieved = ALGORITHMIC bytes of the solve kernel per launch (SURVEY.md §8(d)
+               streaming model, fp64, evaluated from the iteration/evaluation counts the kernel
+               reports) / its average duration measured with HIP events on the launch stream;
+               peak = 8 TB/s HBM3E.  traffic = HBM bytes per launch from rocprofv3 PMC
+               (profiles/*.json, when that summary exists for this workload) else null.
+  cpu_baseline the CPU oracle (fp64 restatement, oracle/) timed on this box's host cores on a
+               bounded sample of the same workload: kind "port", 1 thread (plus an all-core
+               figure in cpu_baseline_allcores).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy rate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="config2", choices=["config2", "config4"])
+    ap.add_argument("--batch", type=int, default=0, help="override trajectories per GPU")
+    ap.add_argument("--iters", type=int, default=50, help="L-BFGS max_iterations (BASELINE: 50)")
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+def workload(args, rank, world_size):
+    from trajectory_planner_amd import synth
+    if args.workload == "config2":
+        B = args.batch or 1024
+        world = synth.make_box_world(synth.SEED_BASE + 2, n=256, n_boxes=200)
+        batch = synth.make_bspline_batch(world, B, 32, synth.SEED_BASE + 2 + 1000 + rank)
+        name = f"configs[1]: {B} B-spline trajs x 32 ctrl pts, 256^3 voxel grid, {args.iters} L-BFGS iters, per GPU"
+    else:
+        B = args.batch or 8192
+        world = synth.make_box_world(synth.SEED_BASE + 4, n=512, n_boxes=800, centre_range=24.0)
+        batch = synth.make_bspline_batch(world, B, 64, synth.SEED_BASE + 4 + 1000 + rank, start_range=16.0)
+        name = f"configs[3] shard: {B} B-spline trajs x 64 ctrl pts, 512^3 voxel grid, {args.iters} L-BFGS iters, per GPU"
+    return world, batch, name
+
+
+def algorithmic_bytes(n, m, iters, evals, gpairs, elem=8):
+    """SURVEY.md §8(d) streaming model (every BLAS-1 pass of the CPU reference touches memory):
+    per iteration k: 4*n*min(m,k) (two-loop reads s_j,y_j twice) + 12*n (xp,gp save; s,y; norms),
+    per evaluation: 7*n + 7*G; elem = 8 bytes in the fp64 mode, 4 in fp32."""
+    import numpy as np
+    it = np.maximum(iters.astype(np.int64) - 1, 0)          # two-loops executed
+    ramp = np.where(it <= m, it * (it + 1) // 2, m * (m + 1) // 2 + (it - m) * m)
+    return elem * (4 * n * ramp + 12 * n * iters.astype(np.int64) + evals.astype(np.int64) * (7 * n + 7 * gpairs))
+
+
+def cpu_baseline(args, seconds, threads):
+    """time the CPU oracle (reference order) on repeats of the config batch; returns traj/s"""
+    import numpy as np
+    import oracle_lib as ol
+    world, batch, _ = workload(args, 0, 1)
+    P = ol.default_params()
+    P.max_iterations = args.iters
+    sub = min(batch.B, 256)
+    from trajectory_planner_amd import synth
+    piece = synth.Batch(batch.ctrl[:sub], np.ascontiguousarray(batch.guide_off[:sub * batch.N + 1]), batch.guide_pv,
+                        batch.guide_unk)
+    if threads == 1:
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            ol.optimize_batch(P, piece)
+            done += sub
+        return done / (time.perf_counter() - t0), done
+    import multiprocessing as mp
+
+    def work(q, secs):
+        d, t = 0, time.perf_counter()
+        while time.perf_counter() - t < secs:
+            ol.optimize_batch(P, piece)
+            d += sub
+        q.put((d, time.perf_counter() - t))
+
+    q = mp.Queue()
+    ps = [mp.Process(target=work, args=(q, seconds)) for _ in range(threads)]
+    t0 = time.perf_counter()
+    [p.start() for p in ps]
+    res = [q.get() for _ in ps]
+    [p.join() for p in ps]
+    wall = time.perf_counter() - t0
+    return sum(d for d, _ in res) / wall, sum(d for d, _ in res)
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_only:
+        # child process: never touches the GPU
+        # the GPU box gives one GPU a 16-core CPU share; never start more workers than that
+        threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+        one, n1 = cpu_baseline(args, args.cpu_seconds, 1)
+        allc, na = cpu_baseline(args, max(4.0, args.cpu_seconds / 2), threads)
+        print(json.dumps({"single": one, "single_n": n1, "all": allc, "all_n": na, "threads": threads}))
+        return
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus and world_size > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
+
+    # CPU baseline first, in a child that never initialises HIP (rank 0, N = 1 only)
+    cpu = None
+    if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload,
+                                "--iters", str(args.iters), "--cpu-seconds", str(args.cpu_seconds)] +
+                               (["--batch", str(args.batch)] if args.batch else []),
+                               capture_output=True, text=True, check=True)
+        cpu = json.loads(child.stdout.strip().splitlines()[-1])
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from trajectory_planner_amd.vigo import PREC_F32, PREC_F64, Vigo, default_params
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    world, batch, wname = workload(args, rank, world_size)
+    P = default_params()
+    P.max_iterations = args.iters
+    v = Vigo(local_rank, P, PREC_F32 if args.precision == "f32" else PREC_F64)
+    v.use_current_stream()
+
+    # ---- voxel snapshot: rank 0 packs, one RCCL broadcast over xGMI, every rank adopts it ----
+    dims = world.voxels.shape
+    nwords = v._lib.vigo_grid_packed_bytes(*dims) // 4
+    t_b0 = time.perf_counter()
+    if rank == 0:
+        packed = v.pack_grid(torch.from_numpy(world.voxels).to(dev))
+    else:
+        packed = torch.empty(nwords, dtype=torch.int32, device=dev)
+    bcast_ms = 0.0
+    if world_size > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_b0 = time.perf_counter()
+        dist.broadcast(packed, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t_b0) * 1e3
+    v.set_grid_packed(packed, dims, world.origin, world.res)
+
+    T = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ctrl0, goff, gpv = T(batch.ctrl), T(batch.guide_off), T(batch.guide_pv)
+    work = ctrl0.clone()
+    B, N = batch.B, batch.N
+    n = 3 * (N - 6)
+    from trajectory_planner_amd.vigo import SolveResult
+    res = SolveResult(work, torch.empty(B, N - 6, 3, dtype=torch.float64, device=dev),
+                      torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.float64, device=dev),
+                      torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev))
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        work.copy_(ctrl0)
+        gunk = v.guides_unknown(gpv) if gpv.shape[0] else None
+        if i is not None:
+            ev0[i].record()
+        v.optimize(work, goff, gpv if gpv.shape[0] else None, gunk, inplace=True, out=res)
+        if i is not None:
+            ev1[i].record()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world_size > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world_size > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    iters = res.iters.cpu().numpy()
+    evals = res.evals.cpu().numpy()
+    gp = np.diff(batch.guide_off).reshape(B, N).sum(1)
+    elem = 4 if args.precision == "f32" else 8
+    alg_bytes = float(algorithmic_bytes(n, P.mem_size, iters, evals, gp, elem).sum())
+    compulsory = float(B * (2 * 3 * N * 8 + 3 * (N - 6) * 8 + 24) + gpv.numel() * 8 + gpv.shape[0])
+
+    if rank == 0:
+        total = B * world_size * args.steps
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", f"pmc_{args.workload}_{args.precision}.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "B-spline trajs/s (32 ctrl pts, 256^3 grid, 50 iters) @1 GPU; % HBM roofline"
+            if args.workload == "config2" else "B-spline trajs/s (64 ctrl pts, 512^3 grid, 50 iters)",
+            "value": total / elapsed,
+            "unit": "trajectories/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic (seeded straight paths + box world, SURVEY.md §8d; no dataset exists for this path)",
+            "config": {"workload": wname, "trajs_per_gpu": B, "ctrl_pts": N, "lbfgs_iters": args.iters,
+                       "mem_size": int(P.mem_size), "g_epsilon": float(P.g_epsilon), "grid": list(dims),
+                       "guide_pairs_per_gpu": int(gpv.shape[0]), "sharding": f"batch-dp{world_size}, no data-path collective",
+                       "mean_iters": float(iters.mean()), "mean_evals": float(evals.mean())},
+            "map_bcast_ms": bcast_ms,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "vigo::k_optimize", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "byte_model": "SURVEY.md §8(d) streaming model x fp64 (state streamed per BLAS-1 pass, as the CPU "
+                                       "reference does); the kernel keeps that state in LDS/VGPRs, so HBM sees only the "
+                                       "compulsory bytes below",
+                         "compulsory_bytes_per_launch": compulsory,
+                         "compulsory_frac": compulsory / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = {"value": cpu["single"], "unit": "trajectories/s", "cores": 1, "kind": "port",
+                                   "sample": f"{cpu['single_n']} solves: repeats of the first 256 trajectories of the same "
+                                             f"batch, oracle/vigo_oracle.c (fp64, reference order) on 1 host thread"}
+            out["cpu_baseline_allcores"] = {"value": cpu["all"], "unit": "trajectories/s", "cores": cpu["threads"],
+                                            "kind": "port", "sample": f"{cpu['all_n']} solves, one process per host core"}
+        print(json.dumps(out))
+    v.close()
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
