@@ -25,7 +25,6 @@ namespace vigo {
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kMaxMem = VIGO_MAX_MEM_SIZE;
 
 // reference status codes, LB:20-80
 enum : int {
@@ -80,13 +79,51 @@ __device__ __forceinline__ float from_next(float v) {
     return __int_as_float(dpp_next_i32(__float_as_int(v)));
 }
 
-// butterfly all-reduce of K independent values inside a GROUP-lane group
+// Butterfly all-reduce of K independent values inside a GROUP-lane group, as VALU-speed DPP
+// moves instead of ds_bpermute round trips.  The tree is the xor butterfly
+// v += lane[i ^ m], m = 1, 2, 4, ..., GROUP/2:
+//   m = 1, 2   quad_perm [1,0,3,2] / [2,3,0,1]
+//   m = 4, 8   row_half_mirror / row_mirror: after the quad steps every lane of a quad holds the
+//              quad sum, so pairing lane i with 7-i (15-i) adds the same two partial sums as
+//              pairing it with i^4 (i^8) — identical bits, fp add being commutative;
+//   m = 16     v_permlane16_swap (gfx950): rows 0/1 and 2/3 exchange, sum = even row + odd row;
+//   m = 32     v_permlane32_swap: the two 32-lane halves exchange.
+// All partners stay inside the group, so an exec-masked sibling group never contributes.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    // every source lane of these patterns lies in the reader's own row: no `old` value needed
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double xor16_sum(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+}
+__device__ __forceinline__ double xor32_sum(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+}
 template <int GROUP, int K>
 __device__ __forceinline__ void group_sum(double (&v)[K]) {
+    static_assert(GROUP == 32 || GROUP == 64, "group is half a wave or a wave");
 #pragma unroll
-    for (int m = 1; m < GROUP; m <<= 1) {
+    for (int q = 0; q < K; ++q) v[q] += dpp_f64<0xB1>(v[q]);   // quad_perm:[1,0,3,2]
 #pragma unroll
-        for (int q = 0; q < K; ++q) v[q] += __shfl_xor(v[q], m, kWave);
+    for (int q = 0; q < K; ++q) v[q] += dpp_f64<0x4E>(v[q]);   // quad_perm:[2,3,0,1]
+#pragma unroll
+    for (int q = 0; q < K; ++q) v[q] += dpp_f64<0x141>(v[q]);  // row_half_mirror
+#pragma unroll
+    for (int q = 0; q < K; ++q) v[q] += dpp_f64<0x140>(v[q]);  // row_mirror
+#pragma unroll
+    for (int q = 0; q < K; ++q) v[q] = xor16_sum(v[q]);
+    if (GROUP == 64) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) v[q] = xor32_sum(v[q]);
     }
 }
 template <int GROUP>
@@ -98,7 +135,17 @@ __device__ __forceinline__ double group_sum1(double v) {
 
 __device__ __forceinline__ double sum3(double a, double b, double c) { return (a + b) + c; }
 
+// one L-BFGS history pair of one control point as it sits in LDS (48 B in fp64: three
+// conflict-free ds_read_b128 per lane, one address register)
+template <typename T>
+struct alignas(16) HPair {
+    T s[3];
+    T y[3];
+};
+
 // per-lane view of one trajectory's inputs
+constexpr int kGuideRegs = 2;  // guide pairs per control point kept in VGPRs (more: re-read from HBM/L2)
+template <typename T>
 struct LaneProblem {
     int N;
     int p;            // control point of this lane
@@ -107,17 +154,61 @@ struct LaneProblem {
     int g_begin, g_end;  // this control point's guide pairs
     const double* gpv;
     const uint8_t* gunk;
+    T gq[kGuideRegs][6];     // the first pairs, loaded once per solve (they never move)
+    bool gqu[kGuideRegs];
     int o_begin, o_end;  // this trajectory's obstacles
     const double* obs;
     double w[4];
 };
 
+// One guide pair's contribution, BT.cpp:839-895.  e == dthresh takes the cubic branch (first
+// else-if wins); the "too far" branch is never scaled by the unknown factor.
+template <typename T>
+__device__ __forceinline__ void guide_pair_term(const DevConst& K, const T (&c)[3], T px, T py, T pz, T vx,
+                                                T vy, T vz, bool unk, double& cd, T (&Gd)[3]) {
+    const T dth = (T)K.dth, da = (T)K.da, db = (T)K.db, dcc = (T)K.dc, uf = (T)K.unc_factor;
+    const T dist = ((c[0] - px) * vx + (c[1] - py) * vy) + (c[2] - pz) * vz;
+    const T e = dth - dist;
+    T ct, k;
+    bool scale = false;
+    if (e <= -dth) {
+        const T ne = -e;
+        ct = (ne * ne) * ne;
+        k = T(3.0) * (ne * ne);
+    } else if (e > T(0) && e <= dth) {
+        ct = (e * e) * e;
+        k = T(-3.0) * (e * e);
+        scale = unk;
+    } else if (e >= dth) {
+        ct = (da * (e * e) + db * e) + dcc;
+        k = -((T(2) * da) * e + db);
+        scale = unk;
+    } else {
+        return;  // -dthresh < e <= 0 (or NaN): no penalty
+    }
+    T gx = k * vx, gy = k * vy, gz = k * vz;
+    if (scale) { ct *= uf; gx *= uf; gy *= uf; gz *= uf; }
+    if (!K.plan_in_z) gz = T(0.0);
+    cd += (double)ct;
+    Gd[0] += gx; Gd[1] += gy; Gd[2] += gz;
+}
+
+template <typename T>
+__device__ __forceinline__ double dot3(const T (&a)[3], const T (&b)[3]) {
+    return sum3((double)a[0] * (double)b[0], (double)a[1] * (double)b[1], (double)a[2] * (double)b[2]);
+}
+
 // ---- cost + gradient at the point held in c (BT.cpp:802-821) ---------------------------
-// T is the element type of points/gradients; sums are fp64.  Returns the weighted total
-// (group-uniform); g receives the weighted gradient on interior lanes, 0 elsewhere.
+// T is the element type of points/gradients; sums are fp64.  g receives the weighted gradient
+// on interior lanes, 0 elsewhere.  ONE 7-value group reduction returns
+//   sums[0..3] = un-weighted distance / smoothness / feasibility / dynamic costs,
+//   sums[4] = g.d, sums[5] = x.x over the free points, sums[6] = g.g
+// (the line search needs g.d after every evaluation, LB:829, and the norms after the last one,
+// LB:1200-1201; fusing them costs three more DPP chains instead of two more reductions).
+// Returns the weighted total cost (group-uniform).
 template <typename T, int GROUP>
-__device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LaneProblem& Q,
-                                                 const T (&c)[3], T (&g)[3], double (&terms)[4]) {
+__device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LaneProblem<T>& Q, const T (&c)[3],
+                                                 const T (&d)[3], T (&g)[3], double (&sums)[7]) {
     const int N = Q.N, p = Q.p;
     // 7-point window c[p-3..p+3] by chained DPP shifts
     T m1[3], m2[3], m3[3], p1[3], p2[3], p3[3];
@@ -132,7 +223,7 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
     }
 
     T Gd[3] = {0, 0, 0}, Gs[3] = {0, 0, 0}, Gf[3] = {0, 0, 0}, Go[3] = {0, 0, 0};
-    double part[4] = {0.0, 0.0, 0.0, 0.0};  // distance, smoothness, feasibility, dynamic
+    double part[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
     // ---- smoothness, BT.cpp:934-950 (gather form of the scatter-add) ----
     {
@@ -162,96 +253,70 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
     {
         const T ts = (T)K.ts_ctrl, tis = (T)K.ts_inv_sqr;
         auto excess = [](T v) -> T { return v > T(1.0) ? v - T(1.0) : (v < T(-1.0) ? v + T(1.0) : T(0.0)); };
-        double cf = 0.0;
+        T evP[3], eaP[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            T evP = excess((p1[a] - c[a]) / ts);    // velocity i = p
-            T evM = excess((c[a] - m1[a]) / ts);    // velocity i = p-1
-            T eaP = excess(((p2[a] - 2 * p1[a]) + c[a]) * tis);    // acc i = p
-            T eaM1 = excess(((p1[a] - 2 * c[a]) + m1[a]) * tis);   // acc i = p-1
-            T eaM2 = excess(((c[a] - 2 * m1[a]) + m2[a]) * tis);   // acc i = p-2
+            evP[a] = excess((p1[a] - c[a]) / ts);                        // velocity i = p
+            eaP[a] = excess(((p2[a] - 2 * p1[a]) + c[a]) * tis);         // acc i = p
+            const T evM = excess((c[a] - m1[a]) / ts);                   // velocity i = p-1
+            const T eaM1 = excess(((p1[a] - 2 * c[a]) + m1[a]) * tis);   // acc i = p-1
+            const T eaM2 = excess(((c[a] - 2 * m1[a]) + m2[a]) * tis);   // acc i = p-2
             if (Q.interior) {
-                T acc = (T(2) * evM) / ts * tis;    // i=p-1: gradient(j,i+1)
-                acc += (T(-2) * evP) / ts * tis;    // i=p  : gradient(j,i)
-                acc += (T(2) * eaM2) * tis;         // i=p-2: gradient(j,i+2)
-                acc += (T(-4) * eaM1) * tis;        // i=p-1: gradient(j,i+1)
-                acc += (T(2) * eaP) * tis;          // i=p  : gradient(j,i)
+                T acc = (T(2) * evM) / ts * tis;       // i=p-1: gradient(j,i+1)
+                acc += (T(-2) * evP[a]) / ts * tis;    // i=p  : gradient(j,i)
+                acc += (T(2) * eaM2) * tis;            // i=p-2: gradient(j,i+2)
+                acc += (T(-4) * eaM1) * tis;           // i=p-1: gradient(j,i+1)
+                acc += (T(2) * eaP[a]) * tis;          // i=p  : gradient(j,i)
                 Gf[a] = acc;
             }
         }
         // cost partial of lane p: velocity i=p (x,y,z) then acceleration i=p (x,y,z)
+        double cf = 0.0;
         if (Q.has_pt && p <= N - 2) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                T ev = excess((p1[a] - c[a]) / ts);
-                cf += (double)((ev * ev) * tis);
-            }
+            for (int a = 0; a < 3; ++a) cf += (double)((evP[a] * evP[a]) * tis);
         }
         if (Q.has_pt && p <= N - 3) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                T ea = excess(((p2[a] - 2 * p1[a]) + c[a]) * tis);
-                cf += (double)(ea * ea);
-            }
+            for (int a = 0; a < 3; ++a) cf += (double)(eaP[a] * eaP[a]);
         }
         part[2] = cf;
     }
 
     // ---- guide-point distance, BT.cpp:823-932 ----
     if (Q.interior) {
-        const T dth = (T)K.dth, da = (T)K.da, db = (T)K.db, dcc = (T)K.dc, uf = (T)K.unc_factor;
         double cd = 0.0;
-        for (int j = Q.g_begin; j < Q.g_end; ++j) {
+        const int cnt = Q.g_end - Q.g_begin;
+#pragma unroll
+        for (int j = 0; j < kGuideRegs; ++j) {
+            if (j < cnt)
+                guide_pair_term<T>(K, c, Q.gq[j][0], Q.gq[j][1], Q.gq[j][2], Q.gq[j][3], Q.gq[j][4], Q.gq[j][5],
+                                   Q.gqu[j], cd, Gd);
+        }
+        for (int j = Q.g_begin + kGuideRegs; j < Q.g_end; ++j) {
             const double* pv = Q.gpv + 6 * (size_t)j;
-            const T px = (T)pv[0], py = (T)pv[1], pz = (T)pv[2];
-            const T vx = (T)pv[3], vy = (T)pv[4], vz = (T)pv[5];
-            const bool unk = Q.gunk ? (Q.gunk[j] != 0) : false;
-            T dist = ((c[0] - px) * vx + (c[1] - py) * vy) + (c[2] - pz) * vz;
-            T e = dth - dist;
-            T ct, k;
-            bool hit = true, scale = false;
-            if (e <= -dth) {                       // too far: never scaled by the unknown factor
-                T ne = -e;
-                ct = (ne * ne) * ne;
-                k = T(3.0) * (ne * ne);
-            } else if (e > T(0) && e <= dth) {     // e == dth lands here
-                ct = (e * e) * e;
-                k = T(-3.0) * (e * e);
-                scale = unk;
-            } else if (e >= dth) {
-                ct = (da * (e * e) + db * e) + dcc;
-                k = -((T(2) * da) * e + db);
-                scale = unk;
-            } else {
-                hit = false; ct = 0; k = 0;
-            }
-            if (hit) {
-                T gx = k * vx, gy = k * vy, gz = k * vz;
-                if (scale) { ct *= uf; gx *= uf; gy *= uf; gz *= uf; }
-                if (!K.plan_in_z) gz = T(0.0);
-                cd += (double)ct;
-                Gd[0] += gx; Gd[1] += gy; Gd[2] += gz;
-            }
+            guide_pair_term<T>(K, c, (T)pv[0], (T)pv[1], (T)pv[2], (T)pv[3], (T)pv[4], (T)pv[5],
+                               Q.gunk ? (Q.gunk[j] != 0) : false, cd, Gd);
         }
         if (K.plan_in_z) {
             // BT.cpp:897-930, reproduced with its x-row gradient and heightDistMax band test
             const T hth = (T)K.hth, ha = (T)K.ha, hb = (T)K.hb, hc = (T)K.hc;
-            T hmin = c[2] - (T)K.min_h, hmax = c[2] - (T)K.max_h;
+            const T hmin = c[2] - (T)K.min_h, hmax = c[2] - (T)K.max_h;
             if (hmin < T(0)) {
-                T e = hth - hmin;
+                const T e = hth - hmin;
                 cd += (double)((ha * (e * e) + hb * e) + hc);
                 Gd[0] += -((T(2) * ha) * e + hb) * T(-1.0);
             } else if (hmin >= T(0) && hmax < hth) {
-                T e = hth - hmin;
+                const T e = hth - hmin;
                 cd += (double)((e * e) * e);
                 Gd[0] += T(-3.0) * (e * e) * T(-1.0);
             }
             if (hmax > T(0)) {
-                T e = hth + hmax;
+                const T e = hth + hmax;
                 cd += (double)((ha * (e * e) + hb * e) + hc);
                 Gd[0] += -((T(2) * ha) * e + hb) * T(1.0);
             } else if (hmax <= T(0) && hmax >= -hth) {
-                T e = hth + hmax;
+                const T e = hth + hmax;
                 cd += (double)((e * e) * e);
                 Gd[0] += T(-3.0) * (e * e) * T(1.0);
             }
@@ -281,11 +346,11 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
                     // no punishment
                 } else if (e > T(0) && e <= thr) {
                     co += (double)((e * e) * e);
-                    T k = T(-3.0) * (e * e);
+                    const T k = T(-3.0) * (e * e);
                     Go[0] += k * gx; Go[1] += k * gy; Go[2] += k * gz;
                 } else if (e >= thr) {
                     co += (double)((oa * (e * e) + ob * e) + oc);
-                    T k = -((T(2) * oa) * e + ob);
+                    const T k = -((T(2) * oa) * e + ob);
                     Go[0] += k * gx; Go[1] += k * gy; Go[2] += k * gz;
                 }
             }
@@ -293,24 +358,22 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
         part[3] = co;
     }
 
-    group_sum<GROUP, 4>(part);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) terms[q] = part[q];
     const T w0 = (T)Q.w[0], w1 = (T)Q.w[1], w2 = (T)Q.w[2], w3 = (T)Q.w[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
         g[a] = Q.interior ? (((w0 * Gd[a] + w1 * Gs[a]) + w2 * Gf[a]) + w3 * Go[a]) : T(0);
+    part[4] = dot3(g, d);
+    part[5] = Q.interior ? dot3(c, c) : 0.0;
+    part[6] = dot3(g, g);
+    group_sum<GROUP, 7>(part);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) sums[q] = part[q];
     return ((Q.w[0] * part[0] + Q.w[1] * part[1]) + Q.w[2] * part[2]) + Q.w[3] * part[3];
 }
 
-template <typename T>
-__device__ __forceinline__ double dot3(const T (&a)[3], const T (&b)[3]) {
-    return sum3((double)a[0] * (double)b[0], (double)a[1] * (double)b[1], (double)a[2] * (double)b[2]);
-}
-
-template <int GROUP>
+template <typename T, int GROUP>
 __device__ __forceinline__ void load_problem(const SolveArgs& A, const DevConst& K, int b, int p,
-                                             LaneProblem& Q) {
+                                             LaneProblem<T>& Q) {
     const int N = A.N;
     Q.N = N;
     Q.p = p;
@@ -322,6 +385,18 @@ __device__ __forceinline__ void load_problem(const SolveArgs& A, const DevConst&
     if (Q.interior && A.guide_off) {
         Q.g_begin = A.guide_off[(size_t)b * N + p];
         Q.g_end = A.guide_off[(size_t)b * N + p + 1];
+    }
+#pragma unroll
+    for (int j = 0; j < kGuideRegs; ++j) {
+        Q.gqu[j] = false;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Q.gq[j][q] = T(0);
+        if (Q.g_begin + j < Q.g_end) {
+            const double* pv = A.guide_pv + 6 * (size_t)(Q.g_begin + j);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) Q.gq[j][q] = (T)pv[q];
+            Q.gqu[j] = A.guide_unk ? (A.guide_unk[Q.g_begin + j] != 0) : false;
+        }
     }
     Q.obs = A.obs;
     if (A.obs_off) {
@@ -348,16 +423,17 @@ __global__ void __launch_bounds__(kWave) k_cost_grad(SolveArgs A, DevConst K) {
     const int p = lane % GROUP;
     const int b = blockIdx.x * TPB + lane / GROUP;
     if (b >= A.B) return;
-    LaneProblem Q;
-    load_problem<GROUP>(A, K, b, p, Q);
+    LaneProblem<T> Q;
+    load_problem<T, GROUP>(A, K, b, p, Q);
     T c[3] = {0, 0, 0};
     if (Q.has_pt) {
         const double* src = A.ctrl + ((size_t)b * A.N + p) * 3;
         c[0] = (T)src[0]; c[1] = (T)src[1]; c[2] = (T)src[2];
     }
     T g[3];
-    double terms[4];
-    double f = eval_cost_grad<T, GROUP>(K, Q, c, g, terms);
+    const T zero[3] = {0, 0, 0};
+    double sums[7];
+    const double f = eval_cost_grad<T, GROUP>(K, Q, c, zero, g, sums);
     if (Q.interior && A.out_grad) {
         double* dst = A.out_grad + ((size_t)b * (A.N - 6) + (p - 3)) * 3;
         dst[0] = (double)g[0]; dst[1] = (double)g[1]; dst[2] = (double)g[2];
@@ -366,13 +442,12 @@ __global__ void __launch_bounds__(kWave) k_cost_grad(SolveArgs A, DevConst K) {
         if (A.out_cost) A.out_cost[b] = f;
         if (A.out_terms) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) A.out_terms[4 * (size_t)b + q] = terms[q];
+            for (int q = 0; q < 4; ++q) A.out_terms[4 * (size_t)b + q] = sums[q];
         }
     }
 }
 
 // ---- More-Thuente helpers (per-lane scalar code, group-uniform values) -------------------
-struct LsPoint { double t, f, d; };
 
 // LB:308-324
 __device__ __forceinline__ double cubic_min(double u, double fu, double du, double v, double fv, double dv) {
@@ -419,63 +494,76 @@ __device__ __forceinline__ double quad_min_secant(double u, double du, double v,
     return v + dv / (dv - du) * a;
 }
 
-// LB:506-714
-__device__ __forceinline__ int trial_interval(LsPoint& X, LsPoint& Y, LsPoint& Tr, double tmin,
-                                              double tmax, int& brackt) {
+// LB:506-714 on scalars held in registers: (xt,xf,xd) best point, (yt,yf,yd) other end,
+// (tt,tf,td) trial; tt receives the new trial step.
+__device__ __forceinline__ int trial_interval(double& xt, double& xf, double& xd, double& yt, double& yf,
+                                              double& yd, double& tt, const double tf, const double td,
+                                              const double tmin, const double tmax, int& brackt) {
     int bound;
-    const int dsign = Tr.d * (X.d / fabs(X.d)) < 0.;
+    const int dsign = td * (xd / fabs(xd)) < 0.;
     double mc, mq, newt;
     if (brackt) {
-        const double lo = X.t <= Y.t ? X.t : Y.t;
-        const double hi = X.t >= Y.t ? X.t : Y.t;
-        if (Tr.t <= lo || hi <= Tr.t) return LBERR_OUTOFINTERVAL;
-        if (0. <= X.d * (Tr.t - X.t)) return LBERR_INCREASEGRADIENT;
+        const double lo = xt <= yt ? xt : yt;
+        const double hi = xt >= yt ? xt : yt;
+        if (tt <= lo || hi <= tt) return LBERR_OUTOFINTERVAL;
+        if (0. <= xd * (tt - xt)) return LBERR_INCREASEGRADIENT;
         if (tmax < tmin) return LBERR_INCORRECT_TMINMAX;
     }
-    if (X.f < Tr.f) {
+    if (xf < tf) {
         brackt = 1;
         bound = 1;
-        mc = cubic_min(X.t, X.f, X.d, Tr.t, Tr.f, Tr.d);
-        mq = quad_min(X.t, X.f, X.d, Tr.t, Tr.f);
-        newt = (fabs(mc - X.t) < fabs(mq - X.t)) ? mc : mc + 0.5 * (mq - mc);
+        mc = cubic_min(xt, xf, xd, tt, tf, td);
+        mq = quad_min(xt, xf, xd, tt, tf);
+        newt = (fabs(mc - xt) < fabs(mq - xt)) ? mc : mc + 0.5 * (mq - mc);
     } else if (dsign) {
         brackt = 1;
         bound = 0;
-        mc = cubic_min(X.t, X.f, X.d, Tr.t, Tr.f, Tr.d);
-        mq = quad_min_secant(X.t, X.d, Tr.t, Tr.d);
-        newt = (fabs(mc - Tr.t) > fabs(mq - Tr.t)) ? mc : mq;
-    } else if (fabs(Tr.d) < fabs(X.d)) {
+        mc = cubic_min(xt, xf, xd, tt, tf, td);
+        mq = quad_min_secant(xt, xd, tt, td);
+        newt = (fabs(mc - tt) > fabs(mq - tt)) ? mc : mq;
+    } else if (fabs(td) < fabs(xd)) {
         bound = 1;
-        mc = cubic_min_bounded(X.t, X.f, X.d, Tr.t, Tr.f, Tr.d, tmin, tmax);
-        mq = quad_min_secant(X.t, X.d, Tr.t, Tr.d);
-        if (brackt) newt = (fabs(Tr.t - mc) < fabs(Tr.t - mq)) ? mc : mq;
-        else        newt = (fabs(Tr.t - mc) > fabs(Tr.t - mq)) ? mc : mq;
+        mc = cubic_min_bounded(xt, xf, xd, tt, tf, td, tmin, tmax);
+        mq = quad_min_secant(xt, xd, tt, td);
+        if (brackt) newt = (fabs(tt - mc) < fabs(tt - mq)) ? mc : mq;
+        else        newt = (fabs(tt - mc) > fabs(tt - mq)) ? mc : mq;
     } else {
         bound = 0;
-        if (brackt)          newt = cubic_min(Tr.t, Tr.f, Tr.d, Y.t, Y.f, Y.d);
-        else if (X.t < Tr.t) newt = tmax;
-        else                 newt = tmin;
+        if (brackt)       newt = cubic_min(tt, tf, td, yt, yf, yd);
+        else if (xt < tt) newt = tmax;
+        else              newt = tmin;
     }
-    if (X.f < Tr.f) {
-        Y = Tr;
-    } else {
-        if (dsign) Y = X;
-        X = Tr;
+    {
+        // LB:664-684 as value selects (pointer-style conditional copies end up in scratch)
+        const bool higher = xf < tf;
+        const bool y_from_x = !higher && dsign;
+        const double nyt = higher ? tt : (y_from_x ? xt : yt);
+        const double nyf = higher ? tf : (y_from_x ? xf : yf);
+        const double nyd = higher ? td : (y_from_x ? xd : yd);
+        const double nxt = higher ? xt : tt;
+        const double nxf = higher ? xf : tf;
+        const double nxd = higher ? xd : td;
+        xt = nxt; xf = nxf; xd = nxd;
+        yt = nyt; yf = nyf; yd = nyd;
     }
     if (tmax < newt) newt = tmax;
     if (newt < tmin) newt = tmin;
     if (brackt && bound) {
-        mq = X.t + 0.66 * (Y.t - X.t);
-        if (X.t < Y.t) { if (mq < newt) newt = mq; }
-        else           { if (newt < mq) newt = mq; }
+        mq = xt + 0.66 * (yt - xt);
+        if (xt < yt) { if (mq < newt) newt = mq; }
+        else         { if (newt < mq) newt = mq; }
     }
-    Tr.t = newt;
+    tt = newt;
     return 0;
 }
 
 // ---- whole-solve kernel (vigo_optimize): BT.cpp:687-718 + LB:1024-1349 -------------------
-// LDS: hist[(slot*2 + {0:s,1:y})*3 + axis][ROW] of T with ROW = TPB*(N-6) columns, then
-//      ys[slot][TPB] doubles.
+// LDS: hist[(slot*2 + {0:s,1:y})*3 + axis][ROW] of T with ROW = TPB*(N-6) columns (each lane
+//      reads and writes only its own column: LDS is a per-lane register extension here, no
+//      cross-lane traffic and no barriers), then ys[slot][TPB] and alpha[age][TPB] doubles.
+// Control flow: an outer trip per L-BFGS iteration (trip 0 = the initial evaluation) with ONE
+// evaluation site inside the line-search loop, so the two groups of a wave re-converge at every
+// iteration boundary and run the (dominant) two-loop recursion together.
 template <typename T, int GROUP>
 __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) {
     constexpr int TPB = kWave / GROUP;
@@ -483,8 +571,9 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
     const int N = A.N, NI = N - 6;
     const int ROW = TPB * NI;
     const int m = K.mem_size;
-    T* hist = reinterpret_cast<T*>(lds_raw);
-    double* ys_tab = reinterpret_cast<double*>(lds_raw + (((size_t)m * 6 * ROW * sizeof(T) + 15) & ~(size_t)15));
+    HPair<T>* hist = reinterpret_cast<HPair<T>*>(lds_raw);
+    double* ys_tab = reinterpret_cast<double*>(lds_raw + (((size_t)m * ROW * sizeof(HPair<T>) + 15) & ~(size_t)15));
+    double* alpha_tab = ys_tab + (size_t)m * TPB;
 
     const int lane = threadIdx.x;
     const int grp = lane / GROUP;
@@ -492,9 +581,14 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
     const int b = blockIdx.x * TPB + grp;
     if (b >= A.B) return;
 
-    LaneProblem Q;
-    load_problem<GROUP>(A, K, b, p, Q);
-    const int col = grp * NI + (p - 3);  // valid on interior lanes only
+    LaneProblem<T> Q;
+    load_problem<T, GROUP>(A, K, b, p, Q);
+    // this lane's history column.  Lanes that own no free point (p < 3, p > N-4) read a
+    // neighbour's column — finite data their zero d/g wipes out — and never write.
+    const int pc = (p < 3) ? 3 : ((p > N - 4) ? N - 4 : p);
+    HPair<T>* hl = hist + (grp * NI + (pc - 3));
+    double* ys_l = ys_tab + grp;
+    double* al_l = alpha_tab + grp;
 
     // x holds this lane's control point: a free variable on interior lanes, a fixed boundary
     // point elsewhere (its g, d, s, y are identically zero so it never moves).
@@ -503,211 +597,218 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
         const double* src = A.ctrl + ((size_t)b * N + p) * 3;
         x[0] = (T)src[0]; x[1] = (T)src[1]; x[2] = (T)src[2];
     }
-    T g[3], xp[3], gp[3], d[3];
-    double terms[4];
+    T g[3] = {0, 0, 0}, xp[3] = {0, 0, 0}, gp[3] = {0, 0, 0}, d[3] = {0, 0, 0};
+    double sums[7];
     int evals = 0;
     int ret = LBERR_UNKNOWN;
-    int k = 0;
+    int k = 0, end = 0;
+    double fx = 0.0, step = 0.0;
+    bool first = true;
 
-    double fx = eval_cost_grad<T, GROUP>(K, Q, x, g, terms);  // LB:1132
-    ++evals;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) d[a] = -g[a];  // LB:1144
-
-    double xnorm, gnorm;
-    {
-        double r[2] = {Q.interior ? dot3(x, x) : 0.0, dot3(g, g)};
-        group_sum<GROUP, 2>(r);
-        xnorm = sqrt(r[0]);
-        gnorm = sqrt(r[1]);
-    }
-    if (xnorm < 1.0) xnorm = 1.0;
-    if (gnorm / xnorm <= K.g_epsilon) {
-        ret = LB_ALREADY_MINIMIZED;  // LB:1154-1157
-    } else {
-        double step = 1.0 / sqrt(group_sum1<GROUP>(dot3(d, d)));  // LB:1163
-        int end = 0;
-        k = 1;
-        for (;;) {
+    for (;;) {  // one trip per L-BFGS iteration; trip 0 only evaluates the start point (LB:1132)
+        // ---------------- line_search_morethuente, LB:716-937 ----------------
+        int ls = 0;
+        int count = 0, brackt = 0, stage1 = 1, uinfo = 0;
+        double dginit = 0.0, finit = 0.0, dgtest = 0.0, width = 0.0, prev_width = 0.0;
+        double xt = 0., xf = 0., xd = 0., yt = 0., yf = 0., yd = 0.;
+        const double stpmin = K.min_step, stpmax = K.max_step;
+        bool run = true;
+        if (!first) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) { xp[a] = x[a]; gp[a] = g[a]; }  // LB:1172-1173
-
-            // ---------------- line_search_morethuente, LB:716-937 ----------------
-            int ls;
-            {
-                const double stpmin = K.min_step, stpmax = K.max_step;
-                int count = 0, brackt = 0, stage1 = 1, uinfo = 0;
-                double dginit = 0.0;
-                if (step <= 0.) {
-                    ls = LBERR_INVALIDPARAMETERS;
-                } else if ((dginit = group_sum1<GROUP>(dot3(g, d))) > 0) {
-                    ls = LBERR_INCREASEGRADIENT;
-                } else {
-                    const double finit = fx;
-                    const double dgtest = K.ftol * dginit;
-                    double width = stpmax - stpmin;
-                    double prev_width = 2.0 * width;
-                    LsPoint X = {0., finit, dginit}, Y = {0., finit, dginit};
-                    double stmin, stmax;
-                    for (;;) {
-                        if (brackt) {
-                            stmin = X.t <= Y.t ? X.t : Y.t;
-                            stmax = X.t >= Y.t ? X.t : Y.t;
-                        } else {
-                            stmin = X.t;
-                            stmax = step + 4.0 * (step - X.t);
-                        }
-                        if (step < stpmin) step = stpmin;
-                        if (stpmax < step) step = stpmax;
-                        if ((brackt && ((step <= stmin || stmax <= step) || K.max_linesearch <= count + 1 || uinfo != 0)) ||
-                            (brackt && (stmax - stmin <= K.xtol * stmax))) {
-                            step = X.t;
-                        }
-                        // x <- xp + step * d  (LB:824-825)
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) x[a] = xp[a] + (T)step * d[a];
-
-                        fx = eval_cost_grad<T, GROUP>(K, Q, x, g, terms);  // LB:828
-                        ++evals;
-                        const double dg = group_sum1<GROUP>(dot3(g, d));
-                        const double ftest1 = finit + step * dgtest;
-                        ++count;
-
-                        if (brackt && ((step <= stmin || stmax <= step) || uinfo != 0)) { ls = LBERR_ROUNDING_ERROR; break; }
-                        if (step == stpmax && fx <= ftest1 && dg <= dgtest) { ls = LBERR_MAXIMUMSTEP; break; }
-                        if (step == stpmin && (ftest1 < fx || dgtest <= dg)) { ls = LBERR_MINIMUMSTEP; break; }
-                        if (brackt && (stmax - stmin) <= K.xtol * stmax) { ls = LBERR_WIDTHTOOSMALL; break; }
-                        if (K.max_linesearch <= count) { ls = LBERR_MAXIMUMLINESEARCH; break; }
-                        if (fx <= ftest1 && fabs(dg) <= K.gtol * (-dginit)) { ls = count; break; }
-
-                        const double cmin = K.ftol <= K.gtol ? K.ftol : K.gtol;
-                        if (stage1 && fx <= ftest1 && cmin * dginit <= dg) stage1 = 0;
-
-                        LsPoint Tr;
-                        if (stage1 && ftest1 < fx && fx <= X.f) {
-                            LsPoint Xm = {X.t, X.f - X.t * dgtest, X.d - dgtest};
-                            LsPoint Ym = {Y.t, Y.f - Y.t * dgtest, Y.d - dgtest};
-                            Tr.t = step; Tr.f = fx - step * dgtest; Tr.d = dg - dgtest;
-                            uinfo = trial_interval(Xm, Ym, Tr, stmin, stmax, brackt);
-                            X.t = Xm.t; Y.t = Ym.t;
-                            X.f = Xm.f + Xm.t * dgtest;
-                            Y.f = Ym.f + Ym.t * dgtest;
-                            X.d = Xm.d + dgtest;
-                            Y.d = Ym.d + dgtest;
-                            step = Tr.t;
-                        } else {
-                            Tr.t = step; Tr.f = fx; Tr.d = dg;
-                            uinfo = trial_interval(X, Y, Tr, stmin, stmax, brackt);
-                            step = Tr.t;
-                        }
-                        if (brackt) {
-                            if (0.66 * prev_width <= fabs(Y.t - X.t)) step = X.t + 0.5 * (Y.t - X.t);
-                            prev_width = width;
-                            width = fabs(Y.t - X.t);
-                        }
-                    }
-                }
-            }
-
-            if (ls < 0) {
-                // LB:1189-1197.  optData_.controlPoints keeps the last trial (BT.cpp:803): write
-                // it out now, then revert x like the reference does.
-                if (Q.has_pt) {
-                    double* dst = A.ctrl + ((size_t)b * N + p) * 3;
-                    dst[0] = (double)x[0]; dst[1] = (double)x[1]; dst[2] = (double)x[2];
-                }
-#pragma unroll
-                for (int a = 0; a < 3; ++a) { x[a] = xp[a]; g[a] = gp[a]; }
-                ret = ls;
-                break;
-            }
-
-            // convergence test, LB:1200-1225
-            {
-                double r[2] = {Q.interior ? dot3(x, x) : 0.0, dot3(g, g)};
-                group_sum<GROUP, 2>(r);
-                xnorm = sqrt(r[0]);
-                gnorm = sqrt(r[1]);
-            }
-            if (xnorm < 1.0) xnorm = 1.0;
-            if (gnorm / xnorm <= K.g_epsilon) { ret = LB_CONVERGENCE; break; }
-            if (K.max_iterations != 0 && K.max_iterations < k + 1) { ret = LBERR_MAXIMUMITERATION; break; }
-
-            // s, y, ys, yy — LB:1264-1276
-            T sv[3], yv[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) { sv[a] = x[a] - xp[a]; yv[a] = g[a] - gp[a]; }
-            if (Q.interior) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    hist[((size_t)(end * 2 + 0) * 3 + a) * ROW + col] = sv[a];
-                    hist[((size_t)(end * 2 + 1) * 3 + a) * ROW + col] = yv[a];
-                }
-            }
-            double ysyy[2] = {dot3(yv, sv), dot3(yv, yv)};
-            group_sum<GROUP, 2>(ysyy);
-            const double ys = ysyy[0], yy = ysyy[1];
-            ys_tab[end * TPB + grp] = ys;
-
-            // two-loop recursion, LB:1286-1316
-            const int bound = (m <= k) ? m : k;
-            ++k;
-            end = (end + 1 == m) ? 0 : end + 1;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) d[a] = -g[a];
-
-            double alpha[kMaxMem];
-#pragma unroll
-            for (int age = 0; age < kMaxMem; ++age) {  // newest -> oldest
-                if (age < bound) {
-                    int j = end - 1 - age;  // ring slot of that age
-                    if (j < 0) j += m;
-                    T sj[3] = {0, 0, 0}, yj[3] = {0, 0, 0};
-                    if (Q.interior) {
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            sj[a] = hist[((size_t)(j * 2 + 0) * 3 + a) * ROW + col];
-                            yj[a] = hist[((size_t)(j * 2 + 1) * 3 + a) * ROW + col];
-                        }
-                    }
-                    double al = group_sum1<GROUP>(dot3(sj, d));
-                    al /= ys_tab[j * TPB + grp];
-                    alpha[age] = al;
-                    const T na = (T)(-al);
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) d[a] += na * yj[a];
-                }
-            }
-            {
-                const T sc = (T)(ys / yy);
-#pragma unroll
-                for (int a = 0; a < 3; ++a) d[a] *= sc;
-            }
-#pragma unroll
-            for (int age = kMaxMem - 1; age >= 0; --age) {  // oldest -> newest
-                if (age < bound) {
-                    int j = end - 1 - age;  // ring slot of that age
-                    if (j < 0) j += m;
-                    T sj[3] = {0, 0, 0}, yj[3] = {0, 0, 0};
-                    if (Q.interior) {
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            sj[a] = hist[((size_t)(j * 2 + 0) * 3 + a) * ROW + col];
-                            yj[a] = hist[((size_t)(j * 2 + 1) * 3 + a) * ROW + col];
-                        }
-                    }
-                    double beta = group_sum1<GROUP>(dot3(yj, d));
-                    beta /= ys_tab[j * TPB + grp];
-                    const T co = (T)(alpha[age] - beta);
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) d[a] += co * sj[a];
-                }
-            }
-            step = 1.0;  // LB:1321
+            dginit = sums[4];  // g.d for the d just built: reduced below with the two-loop's last step
+            if (step <= 0.) { ls = LBERR_INVALIDPARAMETERS; run = false; }
+            else if (0 < dginit) { ls = LBERR_INCREASEGRADIENT; run = false; }
+            finit = fx;
+            dgtest = K.ftol * dginit;
+            width = stpmax - stpmin;
+            prev_width = 2.0 * width;
+            xt = yt = 0.;
+            xf = yf = finit;
+            xd = yd = dginit;
         }
+        while (run) {
+            double stmin = 0., stmax = 0.;
+            if (!first) {
+                if (brackt) {
+                    stmin = xt <= yt ? xt : yt;
+                    stmax = xt >= yt ? xt : yt;
+                } else {
+                    stmin = xt;
+                    stmax = step + 4.0 * (step - xt);
+                }
+                if (step < stpmin) step = stpmin;
+                if (stpmax < step) step = stpmax;
+                if ((brackt && ((step <= stmin || stmax <= step) || K.max_linesearch <= count + 1 || uinfo != 0)) ||
+                    (brackt && (stmax - stmin <= K.xtol * stmax))) {
+                    step = xt;
+                }
+                // x <- xp + step * d  (LB:824-825)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) x[a] = xp[a] + (T)step * d[a];
+            }
+
+            fx = eval_cost_grad<T, GROUP>(K, Q, x, d, g, sums);  // the only evaluation site (LB:828, :1132)
+            ++evals;
+            if (first) break;
+
+            const double dg = sums[4];
+            const double ftest1 = finit + step * dgtest;
+            ++count;
+
+            if (brackt && ((step <= stmin || stmax <= step) || uinfo != 0)) { ls = LBERR_ROUNDING_ERROR; break; }
+            if (step == stpmax && fx <= ftest1 && dg <= dgtest) { ls = LBERR_MAXIMUMSTEP; break; }
+            if (step == stpmin && (ftest1 < fx || dgtest <= dg)) { ls = LBERR_MINIMUMSTEP; break; }
+            if (brackt && (stmax - stmin) <= K.xtol * stmax) { ls = LBERR_WIDTHTOOSMALL; break; }
+            if (K.max_linesearch <= count) { ls = LBERR_MAXIMUMLINESEARCH; break; }
+            if (fx <= ftest1 && fabs(dg) <= K.gtol * (-dginit)) { ls = count; break; }
+
+            const double cmin = K.ftol <= K.gtol ? K.ftol : K.gtol;
+            if (stage1 && fx <= ftest1 && cmin * dginit <= dg) stage1 = 0;
+
+            // LB:883-920: the interval update runs on the modified function while stage1 holds and
+            // the decrease is insufficient; one call site, operands selected here.
+            const bool mod = stage1 && ftest1 < fx && fx <= xf;
+            double axf = mod ? xf - xt * dgtest : xf, axd = mod ? xd - dgtest : xd;
+            double ayf = mod ? yf - yt * dgtest : yf, ayd = mod ? yd - dgtest : yd;
+            const double atf = mod ? fx - step * dgtest : fx, atd = mod ? dg - dgtest : dg;
+            uinfo = trial_interval(xt, axf, axd, yt, ayf, ayd, step, atf, atd, stmin, stmax, brackt);
+            xf = mod ? axf + xt * dgtest : axf;
+            yf = mod ? ayf + yt * dgtest : ayf;
+            xd = mod ? axd + dgtest : axd;
+            yd = mod ? ayd + dgtest : ayd;
+
+            if (brackt) {
+                if (0.66 * prev_width <= fabs(yt - xt)) step = xt + 0.5 * (yt - xt);
+                prev_width = width;
+                width = fabs(yt - xt);
+            }
+        }
+
+        double xnorm = sqrt(sums[5]), gnorm = sqrt(sums[6]);
+        if (first) {
+            first = false;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) d[a] = -g[a];  // LB:1144
+            if (xnorm < 1.0) xnorm = 1.0;
+            if (gnorm / xnorm <= K.g_epsilon) { ret = LB_ALREADY_MINIMIZED; break; }  // LB:1154-1157
+            // d = -g: d.d = g.g and g.d = -(g.g) exactly (negation commutes with every rounding)
+            step = 1.0 / sqrt(sums[6]);  // LB:1163
+            sums[4] = -sums[6];
+            k = 1;
+            end = 0;
+            continue;
+        }
+
+        if (ls < 0) {
+            // LB:1189-1197.  optData_.controlPoints keeps the last trial (BT.cpp:803): write it
+            // out now, then revert x like the reference does.
+            if (Q.has_pt) {
+                double* dst = A.ctrl + ((size_t)b * N + p) * 3;
+                dst[0] = (double)x[0]; dst[1] = (double)x[1]; dst[2] = (double)x[2];
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { x[a] = xp[a]; g[a] = gp[a]; }
+            ret = ls;
+            break;
+        }
+
+        // convergence test, LB:1200-1225 (norms came with the last evaluation)
+        if (xnorm < 1.0) xnorm = 1.0;
+        if (gnorm / xnorm <= K.g_epsilon) { ret = LB_CONVERGENCE; break; }
+        if (K.max_iterations != 0 && K.max_iterations < k + 1) { ret = LBERR_MAXIMUMITERATION; break; }
+
+        // s, y, ys, yy — LB:1264-1276
+        T sv[3], yv[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { sv[a] = x[a] - xp[a]; yv[a] = g[a] - gp[a]; }
+        if (Q.interior) {
+            HPair<T> hp;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { hp.s[a] = sv[a]; hp.y[a] = yv[a]; }
+            hl[end * ROW] = hp;
+        }
+        double ysyy[2] = {dot3(yv, sv), dot3(yv, yv)};
+        group_sum<GROUP, 2>(ysyy);
+        const double ys = ysyy[0], yy = ysyy[1];
+        ys_l[end * TPB] = ys;
+
+        // two-loop recursion, LB:1286-1316.  Rolled, unrolled by two with ping-pong register sets
+        // (A, B): while one history pair is being reduced the next one is already in flight from
+        // LDS, and nothing is copied between steps.
+        const int bound = (m <= k) ? m : k;
+        ++k;
+        int j = end;                                   // slot of the pair just stored (age 0)
+        end = (end + 1 == m) ? 0 : end + 1;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) d[a] = -g[a];
+
+        T sA[3] = {sv[0], sv[1], sv[2]}, yA[3] = {yv[0], yv[1], yv[2]}, sB[3], yB[3];
+        double ysA = ys, ysB = 0.0;
+        auto fetch = [&](int slot, T (&s_)[3], T (&y_)[3], double& ys_) {
+            const HPair<T> h = hl[slot * ROW];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { s_[a] = h.s[a]; y_[a] = h.y[a]; }
+            ys_ = ys_l[slot * TPB];
+        };
+        auto older = [m](int slot) { return slot == 0 ? m - 1 : slot - 1; };
+        auto newer = [m](int slot) { return slot + 1 == m ? 0 : slot + 1; };
+        // LB:1294-1303: alpha_j = (s_j . q) / ys_j ; q -= alpha_j y_j
+        auto down = [&](const T (&s_)[3], const T (&y_)[3], double ys_, int age) {
+            double al = group_sum1<GROUP>(dot3(s_, d));
+            al /= ys_;
+            al_l[age * TPB] = al;
+            const T na = Q.interior ? (T)(-al) : T(0);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) d[a] += na * y_[a];
+        };
+        // LB:1307-1316: beta = (y_j . r) / ys_j ; r += (alpha_j - beta) s_j
+        auto up = [&](const T (&s_)[3], const T (&y_)[3], double ys_, int age) {
+            double beta = group_sum1<GROUP>(dot3(y_, d));
+            beta /= ys_;
+            const T co = Q.interior ? (T)(al_l[age * TPB] - beta) : T(0);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) d[a] += co * s_[a];
+        };
+
+        bool oldest_in_b = false;
+        for (int age = 0; age < bound; age += 2) {  // newest -> oldest
+            const int jb = older(j);
+            if (age + 1 < bound) fetch(jb, sB, yB, ysB);
+            down(sA, yA, ysA, age);
+            if (age + 1 >= bound) break;
+            const int ja = older(jb);
+            if (age + 2 < bound) fetch(ja, sA, yA, ysA);
+            down(sB, yB, ysB, age + 1);
+            if (age + 2 >= bound) { oldest_in_b = true; j = jb; break; }
+            j = ja;
+        }
+        if (oldest_in_b) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { sA[a] = sB[a]; yA[a] = yB[a]; }
+            ysA = ysB;
+        }
+        {
+            const T sc = (T)(ys / yy);  // LB:1305
+#pragma unroll
+            for (int a = 0; a < 3; ++a) d[a] *= sc;
+        }
+        // set A holds the oldest pair (slot j)
+        for (int age = bound - 1; age >= 0; age -= 2) {  // oldest -> newest
+            const int jb = newer(j);
+            if (age >= 1) fetch(jb, sB, yB, ysB);
+            up(sA, yA, ysA, age);
+            if (age < 1) break;
+            const int ja = newer(jb);
+            if (age >= 2) fetch(ja, sA, yA, ysA);
+            up(sB, yB, ysB, age - 1);
+            j = ja;
+        }
+        sums[4] = group_sum1<GROUP>(dot3(g, d));  // dginit of the next line search (LB:746)
+        step = 1.0;  // LB:1321
     }
 
-    // results.  On success/convergence/iteration cap the last evaluated point is x itself.
+    // results.  On success / convergence / iteration cap the last evaluated point is x itself.
     if (ret >= 0 || ret == LBERR_MAXIMUMITERATION) {
         if (Q.has_pt) {
             double* dst = A.ctrl + ((size_t)b * N + p) * 3;
@@ -729,9 +830,9 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
 template <typename T, int GROUP>
 size_t optimize_lds_bytes(int N, int m) {
     const int TPB = kWave / GROUP;
-    size_t h = (size_t)m * 6 * TPB * (N - 6) * sizeof(T);
+    size_t h = (size_t)m * TPB * (N - 6) * sizeof(HPair<T>);
     h = (h + 15) & ~(size_t)15;
-    return h + (size_t)m * TPB * sizeof(double);
+    return h + 2 * (size_t)m * TPB * sizeof(double);
 }
 
 }  // namespace
