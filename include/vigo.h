@@ -239,6 +239,14 @@ int vigo_corridor_check(vigo_handle_t h, int S, int deg, const double* coeffs,
                         const double box[3], double map_res,
                         uint8_t* out_flag, int32_t* out_first, int32_t* out_count);
 
+/*
+ * Replaces: polyTrajOctomap::checkCollision(point3d) (PO.cpp:547-568) for M already-sampled
+ * poses, as the reference's checkCollisionTraj(trajectory, ...) overloads use it (PO.cpp:619-656).
+ *   pts double[M][3] (cast to float like pose2Octomap); out uint8[M].
+ */
+int vigo_box_collision_points(vigo_handle_t h, int64_t M, const double* pts, const double box[3],
+                              double map_res, uint8_t* out);
+
 /* The reference's sample clock: t_k of `for (t = 0; ...; t += delT)` (PS.cpp:1129), i.e. the
  * k-fold floating-point accumulation, evaluated in closed form (host utility, no GPU). */
 double vigo_accumulated_time(double delT, int64_t k);

@@ -375,6 +375,19 @@ int vigo_corridor_check(vigo_handle_t h, int S, int deg, const double* coeffs, c
     return VIGO_OK;
 }
 
+int vigo_box_collision_points(vigo_handle_t h, int64_t M, const double* pts, const double box[3], double map_res, uint8_t* out) {
+    if (!h) return VIGO_ERR_INVALID_ARG;
+    if (M < 0 || !box || !(map_res > 0) || (M > 0 && (!pts || !out))) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_box_collision_points: bad argument");
+    if (!h->has_grid) return fail(h, VIGO_ERR_NO_GRID, "vigo_box_collision_points before vigo_set_grid");
+    for (int a = 0; a < 3; ++a) {
+        double q = h->grid.origin[a] / h->grid.res;
+        if (fabs(q - floor(q + 0.5)) > 1e-6)
+            return fail(h, VIGO_ERR_UNSUPPORTED, "corridor checker needs a grid origin that is a multiple of res (octomap keys)");
+    }
+    VIGO_HIP(h, (hipError_t)vigo::launch_box_points(h->stream, h->grid, M, pts, box, map_res, out));
+    return VIGO_OK;
+}
+
 /* ---- ESDF ----------------------------------------------------------------------------------- */
 
 int vigo_set_esdf(vigo_handle_t h, int nx, int ny, int nz, const double origin[3], double res, const float* dist_dev) {

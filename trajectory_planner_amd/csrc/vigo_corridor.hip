@@ -208,6 +208,40 @@ __global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A)
     }
 }
 
+// ---- box sweep at given sample positions (polyTrajOctomap::checkCollision per pose) -------------
+// One thread per pose; lookups go to the packed planes (L2).  Serves the reference's
+// checkCollisionTraj(trajectory, ...) signatures, where the samples already exist (PO.cpp:619-656).
+__global__ void k_box_points(GridView g, int64_t M, const double* __restrict__ pts, double bx, double by, double bz,
+                             double map_res, double rf, uint8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float fx = (float)pts[3 * i], fy = (float)pts[3 * i + 1], fz = (float)pts[3 * i + 2];  // pose2Octomap
+    const double xmin = fx - bx / 2, xmax = fx + bx / 2;
+    const double ymin = fy - by / 2, ymax = fy + by / 2;
+    const double zmin = fz - bz / 2, zmax = fz + bz / 2;
+    const int xNum = (int)((xmax - xmin) / map_res);
+    const int yNum = (int)((ymax - ymin) / map_res);
+    const int zNum = (int)((zmax - zmin) / map_res);
+    bool hit = false;
+    for (int xi = 0; xi <= xNum && !hit; ++xi) {
+        const float qx = (float)(xmin + xi * map_res);
+        const bool x_out = (qx < g.bmin[0]) || (qx > g.bmax[0]);
+        const int kx = (int)floor(rf * (double)qx) - g.key0[0];
+        for (int yi = 0; yi <= yNum && !hit; ++yi) {
+            const float qy = (float)(ymin + yi * map_res);
+            const bool y_out = (qy < g.bmin[1]) || (qy > g.bmax[1]);
+            const int ky = (int)floor(rf * (double)qy) - g.key0[1];
+            for (int zi = 0; zi <= zNum; ++zi) {
+                const float qz = (float)(zmin + zi * map_res);
+                if (x_out || y_out || (qz < g.bmin[2]) || (qz > g.bmax[2])) { hit = true; break; }
+                const int kz = (int)floor(rf * (double)qz) - g.key0[2];
+                if ((grid_bits_at(g, kx, ky, kz) >> 1) != 0) { hit = true; break; }  // outside -> 7 -> collides
+            }
+        }
+    }
+    out[i] = (uint8_t)hit;
+}
+
 // ---- trilinear ESDF (own definition, see oracle/vigo_oracle.c vgo_esdf_query) ------------
 __global__ void k_esdf_query(EsdfView E, int64_t Q, const double* __restrict__ pts,
                              double* __restrict__ out_d, double* __restrict__ out_g) {
@@ -269,6 +303,15 @@ int launch_corridor_check(hipStream_t s, const GridView& g, int S, int deg, cons
     const int tile_bytes = 32 * 1024;
     A.tile_words_cap = tile_bytes / 4;
     hipLaunchKernelGGL(k_corridor, dim3(S), dim3(kBlock), tile_bytes, s, g, A);
+    return (int)hipGetLastError();
+}
+
+int launch_box_points(hipStream_t s, const GridView& g, int64_t M, const double* pts, const double box[3],
+                      double map_res, uint8_t* out) {
+    if (M <= 0) return hipSuccess;
+    const int block = 256;
+    hipLaunchKernelGGL(k_box_points, dim3((unsigned)((M + block - 1) / block)), dim3(block), 0, s, g, M, pts, box[0],
+                       box[1], box[2], map_res, 1.0 / g.res, out);
     return (int)hipGetLastError();
 }
 

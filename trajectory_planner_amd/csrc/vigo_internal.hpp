@@ -94,6 +94,8 @@ int launch_ctrl_occupancy(hipStream_t s, const GridView& g, int B, int N, const 
 int launch_corridor_check(hipStream_t s, const GridView& g, int S, int deg, const double* coeffs,
                           const int32_t* n_samp, const double* delT, const double box[3],
                           double map_res, uint8_t* out_flag, int32_t* out_first, int32_t* out_count);
+int launch_box_points(hipStream_t s, const GridView& g, int64_t M, const double* pts, const double box[3],
+                      double map_res, uint8_t* out);
 int launch_esdf_query(hipStream_t s, const EsdfView& e, int64_t Q, const double* pts,
                       double* out_dist, double* out_grad);
 

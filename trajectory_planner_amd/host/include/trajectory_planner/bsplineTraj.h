@@ -1,0 +1,148 @@
+/*
+ * bsplineTraj.h — trajPlanner::bsplineTraj with the reference's public interface
+ * (include/trajectory_planner/bsplineTraj.h:87-158) over the MI355X back-end (include/vigo.h).
+ *
+ * Host side (this class): path conditioning, B-spline fit, collision-segment bookkeeping, A*,
+ * guide assignment, the rebound loop's decisions, time re-parameterisation, getters.
+ * Device side (libvigo_hip.so): optimize() = vigo_optimize, the rebound-loop gates
+ * (vigo_traj_collision / vigo_traj_dynamic_collision), isUnknown(guide) = vigo_guides_unknown.
+ *
+ * makePlan() runs one planner (B = 1, link compatibility); makePlanBatch() runs the rebound loops
+ * of many planners in lock-step so that every optimize() of the batch is ONE kernel launch —
+ * that is the configuration the device is built for.
+ */
+#ifndef BSPLINETRAJ_H
+#define BSPLINETRAJ_H
+#include <trajectory_planner/bspline.h>
+#include <trajectory_planner/compat.h>
+#include <trajectory_planner/path_search/astarOcc.h>
+#include <trajectory_planner/utils.h>
+
+#include <memory>
+#include <utility>
+#include <vector>
+
+const int bsplineDegree = 3;
+struct vigo_context;
+
+namespace trajPlanner {
+struct optData {
+    Eigen::MatrixXd controlPoints;
+    std::vector<std::vector<Eigen::Vector3d>> guidePoints;
+    std::vector<std::vector<Eigen::Vector3d>> guideDirections;
+    std::vector<bool> findGuidePoint;
+    std::vector<Eigen::Vector3d> dynamicObstaclesPos;
+    std::vector<Eigen::Vector3d> dynamicObstaclesVel;
+    std::vector<Eigen::Vector3d> dynamicObstaclesSize;
+};
+
+class bsplineTraj {
+private:
+    ros::NodeHandle nh_;
+    double controlPointDistance_ = 0.25;  // bsplineTraj.h:46
+    double controlPointsTs_ = 0.2;        // bsplineTraj.h:47
+    trajPlanner::bspline bspline_;
+    trajPlanner::optData optData_;
+    double ts_, dthresh_, maxVel_, maxAcc_;
+    double weightDistance_, weightSmoothness_, weightFeasibility_, weightDynamicObstacle_;
+    double notCheckRatio_ = 0.0;
+    bool planInZAxis_;
+    double minHeight_, maxHeight_, uncertainAwareFactor_, predHorizon_, distThreshDynamic_, maxPathLength_;
+    Eigen::Vector3d maxObstacleSize_;
+    std::shared_ptr<mapManager::occMap> map_;
+    std::shared_ptr<AStar> pathSearch_;
+    std::vector<std::pair<int, int>> collisionSeg_;
+    std::vector<std::vector<Eigen::Vector3d>> astarPaths_;
+    bool init_ = false;
+    double linearFactor_ = 1.0;
+    std::vector<Eigen::Vector3d> inputPathVis_;
+
+    // device
+    vigo_context* dev_ = nullptr;
+    uint64_t mapVersion_ = 0;
+    int lastStatus_ = 0;
+    bool syncDevice();   // params + map snapshot -> handle; false when no GPU / HIP failure
+
+    // per-planner state of the rebound loop (BT.cpp:611-685) so makePlanBatch can interleave planners
+    struct Rebound {
+        double w0 = 0, wo0 = 0;
+        int failCount = 0;
+        bool done = false, ok = false, needOptimize = true;
+    };
+
+public:
+    bsplineTraj();
+    bsplineTraj(const ros::NodeHandle& nh);
+    ~bsplineTraj();
+    bsplineTraj(const bsplineTraj&) = delete;
+    bsplineTraj& operator=(const bsplineTraj&) = delete;
+    void init(const ros::NodeHandle& nh);
+    void initParam();
+    void setMap(const std::shared_ptr<mapManager::occMap>& map);
+    void updateMaxVel(double maxVel);
+    void updateMaxAcc(double maxAcc);
+    bool inputPathCheck(const nav_msgs::Path& path, nav_msgs::Path& adjustedPath, double dt, double& finalTime);
+    bool fillPath(const nav_msgs::Path& path, nav_msgs::Path& adjustedPath);
+    bool updatePath(const nav_msgs::Path& adjustedPath, const std::vector<Eigen::Vector3d>& startEndConditions);
+    void updateDynamicObstacles(const std::vector<Eigen::Vector3d>& obstaclesPos, const std::vector<Eigen::Vector3d>& obstaclesVel,
+                                const std::vector<Eigen::Vector3d>& obstaclesSize);
+
+    bool makePlan();
+    bool makePlan(nav_msgs::Path& trajectory, bool yaw = true);
+    /* all planners must share one map object; returns per-planner success like makePlan() */
+    static std::vector<bool> makePlanBatch(const std::vector<bsplineTraj*>& planners);
+    void clear();
+    void findCollisionSeg(const Eigen::MatrixXd& controlPoints, std::vector<std::pair<int, int>>& collisionSeg);
+    bool pathSearch(std::vector<std::pair<int, int>>& collisionSeg, std::vector<std::vector<Eigen::Vector3d>>& paths);
+    void assignGuidePointsSemiCircle(const std::vector<std::vector<Eigen::Vector3d>>& paths,
+                                     const std::vector<std::pair<int, int>>& collisionSeg);
+    bool isReguideRequired(std::vector<std::pair<int, int>>& reguideCollisionSeg);
+    bool optimizeTrajectory();
+    int optimize();
+    void adjustPathLengthDirect(const std::vector<Eigen::Vector3d>& path, std::vector<Eigen::Vector3d>& adjustedPath);
+
+    /* the lbfgs_evaluate_t seam (BT.h:118-119) on the device: cost and gradient of x */
+    double costFunction(const double* x, double* grad, const int n);
+
+    void linearFeasibilityReparam();
+    double getLinearReparamTime(double t);
+    double getLinearFactor();
+
+    double getInitTs();
+    double getControlPointTs();
+    double getControlPointDist();
+    trajPlanner::bspline getTrajectory();
+    geometry_msgs::PoseStamped getPose(double t, bool yaw = true);
+    double getDuration();
+    double getTimestep();
+    Eigen::MatrixXd getControlPoints();
+    bool isCurrTrajValid();
+    bool isCurrTrajValid(Eigen::Vector3d& firstCollisionPos);
+    int getLastSolverStatus() const { return lastStatus_; }
+
+    std::vector<Eigen::Vector3d> evalTraj();
+    std::vector<Eigen::Vector3d> evalTraj(double dt);
+    nav_msgs::Path evalTrajToMsg(bool yaw = true);
+    nav_msgs::Path evalTrajToMsg(double dt, bool yaw = true);
+    void pathMsgToEigenPoints(const nav_msgs::Path& path, std::vector<Eigen::Vector3d>& points);
+    void eigenPointsToPathMsg(const std::vector<Eigen::Vector3d>& points, nav_msgs::Path& path);
+
+    bool checkCollisionLine(const Eigen::Vector3d& p1, const Eigen::Vector3d& p2);
+    void shortcutPath(const std::vector<Eigen::Vector3d>& path, std::vector<Eigen::Vector3d>& pathSC);
+    bool findGuidePointSemiCircle(int controlPointIdx, const std::pair<int, int>& seg, const std::vector<Eigen::Vector3d>& path,
+                                  Eigen::Vector3d& guidePoint);
+    bool hasCollisionTrajectory(const Eigen::MatrixXd& controlPoints);
+    bool hasDynamicCollisionTrajectory(const Eigen::MatrixXd& controlPoints);
+
+private:
+    bool indexInCollisionSeg(const std::vector<std::pair<int, int>>& collisionSeg, int idx);
+    int findCollisionSegIndex(const std::vector<std::pair<int, int>>& collisionSeg, int idx);
+    bool isControlPointRequireNewGuide(int controlPointIdx);
+    void reboundBegin(Rebound& r);
+    /* one pass of the loop body of BT.cpp:619-681 given the gate results; sets r.done/ok/needOptimize */
+    void reboundStep(Rebound& r, bool hasCollision, bool hasDynamicCollision, bool timedOut);
+    static void solveBatch(const std::vector<bsplineTraj*>& ps);   // one vigo_optimize for all
+    static void gateBatch(const std::vector<bsplineTraj*>& ps, std::vector<uint8_t>& col, std::vector<uint8_t>& dyn);
+};
+}  // namespace trajPlanner
+#endif

@@ -1,0 +1,948 @@
+// bsplineTraj.cpp — trajPlanner::bsplineTraj over the MI355X back-end.
+//
+// Behaviour follows the reference's bsplineTraj.{h,cpp} (cited per function as BT.cpp / BT.h);
+// the numerics of optimize(), the collision gates and isUnknown(guide) run in libvigo_hip.so
+// through the C ABI of include/vigo.h.  Own implementation: host bookkeeping only.
+#include <trajectory_planner/bsplineTraj.h>
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <set>
+
+#include "../../../include/vigo.h"
+
+using std::cout;
+using std::endl;
+
+namespace {
+
+// RAII device buffer; every HIP failure is reported to the caller as `false`
+struct DevBuf {
+    void* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool upload(const void* src, size_t bytes) {
+        if (bytes > n) {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+            n = 0;
+            if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return false;
+            n = bytes;
+        }
+        return bytes == 0 || hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    bool alloc(size_t bytes) {
+        if (bytes <= n && p) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return false;
+        n = bytes;
+        return true;
+    }
+    bool download(void* dst, size_t bytes) const { return hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost) == hipSuccess; }
+};
+
+double wallSeconds() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+#ifndef VIGO_WITH_ROS
+ros::Time ros::Time::now() {
+    ros::Time t;
+    t.sec = wallSeconds();
+    return t;
+}
+#endif
+
+namespace trajPlanner {
+
+bsplineTraj::bsplineTraj() {}
+
+bsplineTraj::bsplineTraj(const ros::NodeHandle& nh) : nh_(nh) { this->initParam(); }
+
+bsplineTraj::~bsplineTraj() {
+    if (dev_) vigo_destroy(dev_);
+}
+
+void bsplineTraj::init(const ros::NodeHandle& nh) {
+    this->nh_ = nh;
+    this->initParam();
+}
+
+// BT.cpp:24-172: same keys, same fall-back values
+void bsplineTraj::initParam() {
+    auto get = [this](const char* key, double& dst, double fallback) {
+        if (!this->nh_.getParam(key, dst)) dst = fallback;
+    };
+    get("bspline_traj/timestep", ts_, 0.1);
+    get("bspline_traj/distance_threshold", dthresh_, 0.5);
+    get("bspline_traj/max_vel", maxVel_, 1.0);
+    get("bspline_traj/max_acc", maxAcc_, 0.5);
+    get("bspline_traj/weight_distance", weightDistance_, 0.5);
+    get("bspline_traj/weight_smoothness", weightSmoothness_, 1.0);
+    get("bspline_traj/weight_feasibility", weightFeasibility_, 1.0);
+    get("bspline_traj/weight_dynamic_obstacle", weightDynamicObstacle_, 1.0);
+    if (!nh_.getParam("bspline_traj/plan_in_z_axis", planInZAxis_)) planInZAxis_ = true;
+    get("bspline_traj/min_height", minHeight_, 0.5);
+    get("bspline_traj/max_height", maxHeight_, 2.0);
+    get("bspline_traj/uncertain_aware_factor", uncertainAwareFactor_, 2.0);
+    get("bspline_traj/prediction_horizon", predHorizon_, 2.0);
+    get("bspline_traj/distance_threshold_dynamic", distThreshDynamic_, 1.0);
+    get("bspline_traj/max_path_length", maxPathLength_, 7.0);
+    std::vector<double> mos;
+    if (!nh_.getParam("bspline_traj/max_obstacle_size", mos) || mos.size() < 3) maxObstacleSize_ = Eigen::Vector3d(10.0, 10.0, 10.0);
+    else maxObstacleSize_ = Eigen::Vector3d(mos[0], mos[1], mos[2]);
+}
+
+// BT.cpp:187-195
+void bsplineTraj::setMap(const std::shared_ptr<mapManager::occMap>& map) {
+    this->map_ = map;
+    this->pathSearch_.reset(new AStar);
+    int maxGridX = 2 * int(this->maxObstacleSize_(0) / this->map_->getRes());
+    int maxGridY = 2 * int(this->maxObstacleSize_(1) / this->map_->getRes());
+    int maxGridZ = 2 * int(this->maxObstacleSize_(2) / this->map_->getRes());
+    this->pathSearch_->initGridMap(map, Eigen::Vector3i(maxGridX, maxGridY, maxGridZ), this->minHeight_, this->maxHeight_);
+    this->mapVersion_ = 0;  // force a new device snapshot
+}
+
+void bsplineTraj::updateMaxVel(double maxVel) { this->maxVel_ = maxVel; }
+void bsplineTraj::updateMaxAcc(double maxAcc) { this->maxAcc_ = maxAcc; }
+
+// handle creation, parameter push and (re)snapshot of the map when its version moved
+bool bsplineTraj::syncDevice() {
+    if (!dev_) {
+        if (vigo_create(&dev_, 0) != VIGO_OK) {
+            cout << "[BsplineTraj]: no HIP device for the ViGO back-end (there is no CPU fallback)." << endl;
+            dev_ = nullptr;
+            return false;
+        }
+    }
+    vigo_params_t P;
+    vigo_default_params(&P);
+    P.dthresh = dthresh_;
+    P.dist_thresh_dynamic = distThreshDynamic_;
+    P.ts_ctrl = controlPointsTs_;
+    P.ts = ts_;
+    P.pred_horizon = predHorizon_;
+    P.uncertain_factor = uncertainAwareFactor_;
+    P.w_distance = weightDistance_;
+    P.w_smoothness = weightSmoothness_;
+    P.w_feasibility = weightFeasibility_;
+    P.w_dynamic = weightDynamicObstacle_;
+    P.min_height = minHeight_;
+    P.max_height = maxHeight_;
+    P.plan_in_z = planInZAxis_ ? 1 : 0;
+    P.mem_size = 16;          // BT.cpp:697
+    P.max_iterations = 200;   // BT.cpp:698
+    P.g_epsilon = 0.01;       // BT.cpp:699
+    if (vigo_set_params(dev_, &P) != VIGO_OK) return false;
+    if (map_ && mapVersion_ != map_->version) {
+        const double o[3] = {map_->origin()(0), map_->origin()(1), map_->origin()(2)};
+        if (vigo_set_grid_host(dev_, map_->nx(), map_->ny(), map_->nz(), o, map_->getRes(), map_->voxels().data()) != VIGO_OK)
+            return false;
+        mapVersion_ = map_->version;
+    }
+    return true;
+}
+
+// BT.cpp:207-245
+bool bsplineTraj::inputPathCheck(const nav_msgs::Path& path, nav_msgs::Path& adjustedPath, double dt, double& finalTime) {
+    if (path.poses.size() == 0) return true;
+    std::vector<Eigen::Vector3d> curveFitPoints, adjustedCurveFitPoints;
+    this->pathMsgToEigenPoints(path, curveFitPoints);
+    this->adjustPathLengthDirect(curveFitPoints, adjustedCurveFitPoints);
+    for (size_t i = 0; i + 1 < adjustedCurveFitPoints.size(); ++i) {
+        double dist = (adjustedCurveFitPoints[i] - adjustedCurveFitPoints[i + 1]).norm();
+        if (dist > this->controlPointDistance_ * 1.5) return false;
+    }
+    Eigen::Vector3d prevPoint;
+    std::vector<Eigen::Vector3d> adjustedPoints;
+    for (size_t i = 0; i < adjustedCurveFitPoints.size(); ++i) {
+        Eigen::Vector3d p = adjustedCurveFitPoints[i];
+        if (i == 0) {
+            adjustedPoints.push_back(p);
+            prevPoint = p;
+        } else if ((p - prevPoint).norm() >= this->controlPointDistance_ * 0.8) {
+            adjustedPoints.push_back(p);
+            prevPoint = p;
+        }
+    }
+    adjustedPoints.push_back(adjustedPoints.back());
+    this->eigenPointsToPathMsg(adjustedPoints, adjustedPath);
+    finalTime = (adjustedCurveFitPoints.size() - 1) * dt;
+    return true;
+}
+
+// BT.cpp:247-288
+bool bsplineTraj::fillPath(const nav_msgs::Path& path, nav_msgs::Path& adjustedPath) {
+    const int n = int(path.poses.size());
+    if (n <= 1) return false;
+    auto P = [&](int i) { return Eigen::Vector3d(path.poses[i].pose.position.x, path.poses[i].pose.position.y, path.poses[i].pose.position.z); };
+    std::vector<Eigen::Vector3d> out;
+    if (n == 2) {
+        Eigen::Vector3d ps = P(0), pf = P(1);
+        out = {ps, (pf - ps) / 3.0 + ps, 2.0 * (pf - ps) / 3.0 + ps, pf};
+    } else if (n == 3) {
+        Eigen::Vector3d ps = P(0), pm = P(1), pf = P(2);
+        out = {ps, (ps + pm) / 2.0, pm, (pm + pf) / 2.0, pf};
+    } else {
+        adjustedPath = path;
+        return true;
+    }
+    adjustedPath.poses.clear();
+    for (const auto& q : out) {
+        geometry_msgs::PoseStamped ps;
+        ps.pose.position.x = q(0); ps.pose.position.y = q(1); ps.pose.position.z = q(2);
+        adjustedPath.poses.push_back(ps);
+    }
+    return true;
+}
+
+// BT.cpp:290-323
+bool bsplineTraj::updatePath(const nav_msgs::Path& adjustedPath, const std::vector<Eigen::Vector3d>& startEndConditions) {
+    if (adjustedPath.poses.empty() || !map_) return false;
+    Eigen::Vector3d goal(adjustedPath.poses.back().pose.position.x, adjustedPath.poses.back().pose.position.y,
+                         adjustedPath.poses.back().pose.position.z);
+    if (this->map_->isInflatedOccupied(goal)) {
+        cout << "[bsplineTraj]: Invalid goal position: " << goal(0) << " " << goal(1) << " " << goal(2) << endl;
+        return false;
+    }
+    std::vector<Eigen::Vector3d> adjustedPathVec, inputPathVec;
+    this->pathMsgToEigenPoints(adjustedPath, adjustedPathVec);
+    this->adjustPathLengthDirect(adjustedPathVec, inputPathVec);
+    nav_msgs::Path inputPath;
+    this->eigenPointsToPathMsg(inputPathVec, inputPath);
+    if (inputPath.poses.size() < 4) {
+        if (!this->fillPath(adjustedPath, inputPath)) {
+            cout << "[bsplineTraj]: Input path point size is less (or equal) than 1." << endl;
+            return false;
+        }
+    }
+    this->clear();
+    std::vector<Eigen::Vector3d> adjustedCurveFitPoints;
+    this->pathMsgToEigenPoints(inputPath, adjustedCurveFitPoints);
+    Eigen::MatrixXd controlPoints;
+    if (!trajPlanner::bspline::parameterizeToBspline(this->controlPointsTs_, adjustedCurveFitPoints, startEndConditions, controlPoints))
+        return false;  // the reference exit(0)s here (bspline.cpp:80-91)
+    this->optData_.controlPoints = controlPoints;
+    int controlPointNum = controlPoints.cols();
+    this->optData_.guidePoints.assign(controlPointNum, {});
+    this->optData_.guideDirections.assign(controlPointNum, {});
+    this->optData_.findGuidePoint.assign(controlPointNum, false);
+    this->init_ = true;
+    this->inputPathVis_ = adjustedCurveFitPoints;
+    return true;
+}
+
+void bsplineTraj::updateDynamicObstacles(const std::vector<Eigen::Vector3d>& obstaclesPos, const std::vector<Eigen::Vector3d>& obstaclesVel,
+                                         const std::vector<Eigen::Vector3d>& obstaclesSize) {
+    this->optData_.dynamicObstaclesPos = obstaclesPos;
+    this->optData_.dynamicObstaclesVel = obstaclesVel;
+    this->optData_.dynamicObstaclesSize = obstaclesSize;
+}
+
+// BT.cpp:333-385
+bool bsplineTraj::makePlan() {
+    std::vector<bsplineTraj*> one{this};
+    return makePlanBatch(one)[0];
+}
+
+bool bsplineTraj::makePlan(nav_msgs::Path& trajectory, bool yaw) {
+    bool success = this->makePlan();
+    trajectory = this->evalTrajToMsg(yaw);
+    return success;
+}
+
+void bsplineTraj::clear() {
+    this->optData_.guidePoints.clear();
+    this->optData_.guideDirections.clear();
+    this->optData_.dynamicObstaclesPos.clear();
+    this->optData_.dynamicObstaclesVel.clear();
+    this->optData_.dynamicObstaclesSize.clear();
+    this->collisionSeg_.clear();
+    this->astarPaths_.clear();
+}
+
+// BT.cpp:403-445 (incl. the corner case that can duplicate a segment, :426-430)
+void bsplineTraj::findCollisionSeg(const Eigen::MatrixXd& controlPoints, std::vector<std::pair<int, int>>& collisionSeg) {
+    collisionSeg.clear();
+    bool previousHasCollision = false;
+    const int N = controlPoints.cols();
+    int endIdx = int((N - bsplineDegree - 1) - this->notCheckRatio_ * (N - 2 * bsplineDegree));
+    int pairStartIdx = bsplineDegree, pairEndIdx = bsplineDegree;
+    for (int i = bsplineDegree; i <= endIdx; ++i) {
+        Eigen::Vector3d p = controlPoints.col(i);
+        bool hasCollision = this->map_->isInflatedOccupied(p);
+        if (hasCollision != previousHasCollision) {
+            if (hasCollision) {
+                pairStartIdx = i - 1;
+            } else {
+                pairEndIdx = i;
+                collisionSeg.push_back({pairStartIdx, pairEndIdx});
+            }
+        }
+        if (hasCollision && i == endIdx - 1) {
+            pairEndIdx = N - 1;
+            collisionSeg.push_back({pairStartIdx, pairEndIdx});
+        }
+        if (i != bsplineDegree && !previousHasCollision && !hasCollision) {
+            if (this->map_->isInflatedOccupiedLine(controlPoints.col(i - 1), p)) collisionSeg.push_back({i - 1, i});
+        }
+        previousHasCollision = hasCollision;
+    }
+}
+
+// BT.cpp:447-514 (merge bookkeeping reproduced as written, Appendix B of SURVEY.md)
+bool bsplineTraj::pathSearch(std::vector<std::pair<int, int>>& collisionSeg, std::vector<std::vector<Eigen::Vector3d>>& paths) {
+    paths.clear();
+    std::vector<int> mergeIndices;
+    int collisionSegNum = int(collisionSeg.size());
+    for (int i = 0; i < collisionSegNum; ++i) {
+        std::pair<int, int> seg = collisionSeg[i];
+        Eigen::Vector3d pStart = this->optData_.controlPoints.col(seg.first);
+        Eigen::Vector3d pEnd = this->optData_.controlPoints.col(seg.second);
+        if (this->pathSearch_->AstarSearch(this->map_->getRes(), pStart, pEnd)) {
+            std::vector<Eigen::Vector3d> searchedPath = this->pathSearch_->getPath();
+            searchedPath[0] = pStart;
+            searchedPath.push_back(pEnd);
+            paths.push_back(searchedPath);
+        } else {
+            if (i + 1 < collisionSegNum) {
+                std::pair<int, int> nextSeg = collisionSeg[i + 1];
+                if (nextSeg.first - seg.second <= 2) {
+                    Eigen::Vector3d pEnd2 = this->optData_.controlPoints.col(nextSeg.second);
+                    if (this->pathSearch_->AstarSearch(this->map_->getRes(), pStart, pEnd2)) {
+                        std::vector<Eigen::Vector3d> searchedPath = this->pathSearch_->getPath();
+                        searchedPath[0] = pStart;
+                        searchedPath.push_back(pEnd2);
+                        paths.push_back(searchedPath);
+                        mergeIndices.push_back(i);
+                        ++i;
+                        continue;
+                    }
+                }
+            }
+            cout << "[BsplineTraj]: Path Search Error. Force return." << endl;
+            return false;
+        }
+    }
+    if (!mergeIndices.empty()) {
+        int midx = 0;
+        std::vector<std::pair<int, int>> collisionSegTemp;
+        for (int i = 0; i < collisionSegNum; ++i) {
+            if (midx < int(mergeIndices.size()) && i == mergeIndices[midx]) {
+                collisionSegTemp.push_back({collisionSeg[i].first, collisionSeg[i + 1].second});
+                ++i;
+                ++midx;
+            } else {
+                collisionSeg.push_back(collisionSeg[i]);  // BT.cpp:507 pushes into the input...
+            }
+        }
+        collisionSeg = collisionSegTemp;  // ...and :510 overwrites it: unmerged segments are dropped
+    }
+    return true;
+}
+
+// BT.h:196-204
+bool bsplineTraj::checkCollisionLine(const Eigen::Vector3d& p1, const Eigen::Vector3d& p2) {
+    for (double a = 0.0; a <= 1.0; a += this->map_->getRes()) {
+        Eigen::Vector3d pMid = a * p1 + (1 - a) * p2;
+        if (this->map_->isInflatedOccupied(pMid)) return true;
+    }
+    return false;
+}
+
+// BT.h:206-240
+void bsplineTraj::shortcutPath(const std::vector<Eigen::Vector3d>& path, std::vector<Eigen::Vector3d>& pathSC) {
+    pathSC.clear();
+    size_t ptr1 = 0, ptr2 = 2;
+    pathSC.push_back(path[ptr1]);
+    if (path.size() == 1) return;
+    if (path.size() == 2) { pathSC.push_back(path[1]); return; }
+    while (true) {
+        if (ptr2 > path.size() - 1) break;
+        if (!this->checkCollisionLine(path[ptr1], path[ptr2])) {
+            if (ptr2 >= path.size() - 1) { pathSC.push_back(path[ptr2]); break; }
+            ++ptr2;
+        } else {
+            pathSC.push_back(path[ptr2 - 1]);
+            ptr1 = ptr2 - 1;
+            ptr2 = ptr1 + 2;
+        }
+    }
+}
+
+// BT.h:251-304
+bool bsplineTraj::findGuidePointSemiCircle(int controlPointIdx, const std::pair<int, int>& seg,
+                                           const std::vector<Eigen::Vector3d>& path, Eigen::Vector3d& guidePoint) {
+    double minAngle = 0.0, maxAngle = PI_const;
+    int numControlpoints = seg.second - seg.first - 1;
+    double targetAngle;
+    Eigen::Vector3d pseudo;
+    if (numControlpoints != 0) {
+        int order = controlPointIdx - seg.first;
+        targetAngle = order * PI_const / (numControlpoints + 2);
+        targetAngle = std::min(std::max(minAngle, targetAngle), maxAngle);
+        double ratio = double(order) / double(numControlpoints + 1.0);
+        pseudo = ratio * (path.back() - path[0]) + path[0];
+    } else {
+        targetAngle = PI_const / 2.0;
+        pseudo = (path[0] + path.back()) / 2.0;
+    }
+    Eigen::Vector3d direction = path[0] - pseudo;
+    for (size_t i = 0; i + 1 < path.size(); ++i) {
+        Eigen::Vector3d wpCurr = path[i], wpNext = path[i + 1];
+        double angleCurr = angleBetweenVectors(direction, wpCurr - pseudo);
+        double angleNext = angleBetweenVectors(direction, wpNext - pseudo);
+        if (targetAngle >= angleCurr && targetAngle <= angleNext) {
+            double prevAngleDiff = 0.0;
+            Eigen::Vector3d prevTempPoint;
+            for (double a = 1.0; a >= 0.0; a -= 0.1) {
+                Eigen::Vector3d tempPoint = a * wpCurr + (1 - a) * wpNext;
+                double angleDiff = angleBetweenVectors(direction, tempPoint - pseudo) - targetAngle;
+                if (angleDiff == 0) { guidePoint = tempPoint; return true; }
+                if (angleDiff * prevAngleDiff < 0) {
+                    double totalDiff = std::abs(angleDiff) + std::abs(prevAngleDiff);
+                    guidePoint = std::abs(prevAngleDiff) / totalDiff * (tempPoint - prevTempPoint) + prevTempPoint;
+                    return true;
+                }
+                prevAngleDiff = angleDiff;
+                prevTempPoint = tempPoint;
+            }
+        }
+    }
+    return false;
+}
+
+// BT.cpp:517-571
+void bsplineTraj::assignGuidePointsSemiCircle(const std::vector<std::vector<Eigen::Vector3d>>& paths,
+                                              const std::vector<std::pair<int, int>>& collisionSeg) {
+    std::vector<std::vector<Eigen::Vector3d>> pathsSC;
+    for (const auto& p : paths) {
+        std::vector<Eigen::Vector3d> sc;
+        this->shortcutPath(p, sc);
+        pathsSC.push_back(sc);
+    }
+    const int N = this->optData_.controlPoints.cols();
+    Eigen::Vector3d guidePoint, guideDirection;
+    for (size_t i = 0; i < collisionSeg.size() && i < pathsSC.size(); ++i) {
+        const std::pair<int, int> seg = collisionSeg[i];
+        const std::vector<Eigen::Vector3d>& path = pathsSC[i];
+        for (int idx = seg.first + 1; idx < seg.second; ++idx) {
+            if (idx < 0 || idx >= N) continue;
+            this->findGuidePointSemiCircle(idx, seg, path, guidePoint);
+            this->optData_.guidePoints[idx].push_back(guidePoint);
+            Eigen::Vector3d diff = guidePoint - this->optData_.controlPoints.col(idx);
+            this->optData_.guideDirections[idx].push_back(diff / diff.norm());
+        }
+        if (seg.second - seg.first - 1 == 0) {  // line collision
+            this->findGuidePointSemiCircle(seg.first, seg, path, guidePoint);
+            Eigen::Vector3d midPoint = (this->optData_.controlPoints.col(seg.first) + this->optData_.controlPoints.col(seg.second)) / 2.0;
+            Eigen::Vector3d diff = guidePoint - midPoint;
+            guideDirection = diff / diff.norm();
+            for (int idx = seg.first - 1; idx <= seg.second + 1; ++idx) {
+                if (idx >= bsplineDegree && idx <= N - bsplineDegree - 1) {
+                    this->optData_.guidePoints[idx].push_back(guidePoint);
+                    this->optData_.guideDirections[idx].push_back(guideDirection);
+                }
+            }
+        }
+    }
+}
+
+bool bsplineTraj::indexInCollisionSeg(const std::vector<std::pair<int, int>>& collisionSeg, int idx) {
+    for (const auto& seg : collisionSeg)
+        if (idx >= seg.first && idx <= seg.second) return true;
+    return false;
+}
+
+int bsplineTraj::findCollisionSegIndex(const std::vector<std::pair<int, int>>& collisionSeg, int idx) {
+    int k = 0;
+    for (const auto& seg : collisionSeg) {
+        if (idx >= seg.first && idx <= seg.second) return k;
+        ++k;
+    }
+    return -1;
+}
+
+// BT.h:417-429
+bool bsplineTraj::isControlPointRequireNewGuide(int controlPointIdx) {
+    Eigen::Vector3d c = this->optData_.controlPoints.col(controlPointIdx);
+    for (size_t i = 0; i < this->optData_.guidePoints[controlPointIdx].size(); ++i) {
+        double dist = (c - this->optData_.guidePoints[controlPointIdx][i]).dot(this->optData_.guideDirections[controlPointIdx][i]);
+        if (this->dthresh_ - dist > 0) return false;
+    }
+    return true;
+}
+
+// BT.cpp:573-608 with compareCollisionSeg (BT.h:379-403) inlined
+bool bsplineTraj::isReguideRequired(std::vector<std::pair<int, int>>& reguideCollisionSeg) {
+    std::vector<std::pair<int, int>> prev = this->collisionSeg_;
+    this->findCollisionSeg(this->optData_.controlPoints, this->collisionSeg_);
+    std::vector<int> fresh, overlapped;
+    for (const auto& s : this->collisionSeg_) {
+        for (int i = s.first + 1; i <= s.second - 1; ++i) (indexInCollisionSeg(prev, i) ? overlapped : fresh).push_back(i);
+        if (s.second - s.first - 1 == 0)
+            for (int i = s.first; i <= s.second; ++i) (indexInCollisionSeg(prev, i) ? overlapped : fresh).push_back(i);
+    }
+    std::set<int> segIdx;
+    for (int i : fresh) segIdx.insert(findCollisionSegIndex(this->collisionSeg_, i));
+    for (int i : overlapped)
+        if (this->isControlPointRequireNewGuide(i)) segIdx.insert(findCollisionSegIndex(this->collisionSeg_, i));
+    segIdx.erase(-1);
+    if (segIdx.empty()) return false;
+    for (int s : segIdx) reguideCollisionSeg.push_back(this->collisionSeg_[s]);
+    return true;
+}
+
+// ---- device calls ---------------------------------------------------------------------
+
+namespace {
+// flattens the planners' optData into the batch layouts of include/vigo.h
+struct HostBatch {
+    int B = 0, N = 0;
+    std::vector<double> ctrl, gpv, obs, weights;
+    std::vector<int32_t> goff, ooff;
+};
+}  // namespace
+
+void bsplineTraj::solveBatch(const std::vector<bsplineTraj*>& ps) {
+    // groups of equal N share a launch (vigo_optimize takes one N per call)
+    std::vector<bool> doneMask(ps.size(), false);
+    for (size_t a = 0; a < ps.size(); ++a) {
+        if (doneMask[a]) continue;
+        const int N = ps[a]->optData_.controlPoints.cols();
+        std::vector<bsplineTraj*> grp;
+        for (size_t b = a; b < ps.size(); ++b)
+            if (!doneMask[b] && ps[b]->optData_.controlPoints.cols() == N) { grp.push_back(ps[b]); doneMask[b] = true; }
+        bsplineTraj* lead = grp[0];
+        for (auto* p : grp) p->lastStatus_ = VIGO_ERR_HIP;
+        if (N < 7 || N > VIGO_MAX_CTRL_POINTS || !lead->syncDevice()) continue;
+        HostBatch hb;
+        hb.B = (int)grp.size();
+        hb.N = N;
+        hb.goff.push_back(0);
+        hb.ooff.push_back(0);
+        for (auto* p : grp) {
+            const double* c = p->optData_.controlPoints.data();
+            hb.ctrl.insert(hb.ctrl.end(), c, c + 3 * N);
+            for (int i = 0; i < N; ++i) {
+                const size_t cnt = i < (int)p->optData_.guidePoints.size() ? p->optData_.guidePoints[i].size() : 0;
+                for (size_t j = 0; j < cnt; ++j) {
+                    const Eigen::Vector3d& g = p->optData_.guidePoints[i][j];
+                    const Eigen::Vector3d& v = p->optData_.guideDirections[i][j];
+                    for (int q = 0; q < 3; ++q) hb.gpv.push_back(g(q));
+                    for (int q = 0; q < 3; ++q) hb.gpv.push_back(v(q));
+                }
+                hb.goff.push_back((int32_t)(hb.gpv.size() / 6));
+            }
+            for (size_t j = 0; j < p->optData_.dynamicObstaclesPos.size(); ++j) {
+                for (int q = 0; q < 3; ++q) hb.obs.push_back(p->optData_.dynamicObstaclesPos[j](q));
+                for (int q = 0; q < 3; ++q) hb.obs.push_back(p->optData_.dynamicObstaclesVel[j](q));
+                for (int q = 0; q < 3; ++q) hb.obs.push_back(p->optData_.dynamicObstaclesSize[j](q));
+            }
+            hb.ooff.push_back((int32_t)(hb.obs.size() / 9));
+            hb.weights.push_back(p->weightDistance_);
+            hb.weights.push_back(p->weightSmoothness_);
+            hb.weights.push_back(p->weightFeasibility_);
+            hb.weights.push_back(p->weightDynamicObstacle_);
+        }
+        const size_t G = hb.gpv.size() / 6;
+        DevBuf dCtrl, dGoff, dGpv, dGunk, dOoff, dObs, dW, dStatus;
+        bool ok = dCtrl.upload(hb.ctrl.data(), hb.ctrl.size() * 8) && dGoff.upload(hb.goff.data(), hb.goff.size() * 4) &&
+                  dGpv.upload(hb.gpv.data(), hb.gpv.size() * 8) && dGunk.alloc(G) && dOoff.upload(hb.ooff.data(), hb.ooff.size() * 4) &&
+                  dObs.upload(hb.obs.data(), hb.obs.size() * 8) && dW.upload(hb.weights.data(), hb.weights.size() * 8) &&
+                  dStatus.alloc(hb.B * 4);
+        if (!ok) continue;
+        vigo_handle_t h = lead->dev_;
+        // map_->isUnknown(guidePoint), BT.cpp:841, hoisted out of the solve
+        if (G && vigo_guides_unknown(h, (int64_t)G, (const double*)dGpv.p, (uint8_t*)dGunk.p) != VIGO_OK) continue;
+        if (vigo_optimize(h, hb.B, N, (double*)dCtrl.p, (const int32_t*)dGoff.p, G ? (const double*)dGpv.p : nullptr,
+                          G ? (const uint8_t*)dGunk.p : nullptr, (const int32_t*)dOoff.p,
+                          hb.obs.empty() ? nullptr : (const double*)dObs.p, 0, (const double*)dW.p, nullptr,
+                          (int32_t*)dStatus.p, nullptr, nullptr, nullptr) != VIGO_OK) {
+            cout << "[BsplineTraj]: vigo_optimize failed: " << vigo_last_error(h) << endl;
+            continue;
+        }
+        std::vector<int32_t> status(hb.B);
+        if (hipDeviceSynchronize() != hipSuccess || !dCtrl.download(hb.ctrl.data(), hb.ctrl.size() * 8) ||
+            !dStatus.download(status.data(), status.size() * 4))
+            continue;
+        for (int b = 0; b < hb.B; ++b) {
+            // optData_.controlPoints = the last evaluated point, as costFunction leaves it (BT.cpp:803)
+            std::memcpy(grp[b]->optData_.controlPoints.data(), hb.ctrl.data() + (size_t)b * 3 * N, sizeof(double) * 3 * N);
+            grp[b]->lastStatus_ = status[b];
+        }
+    }
+}
+
+void bsplineTraj::gateBatch(const std::vector<bsplineTraj*>& ps, std::vector<uint8_t>& col, std::vector<uint8_t>& dyn) {
+    col.assign(ps.size(), 1);
+    dyn.assign(ps.size(), 0);
+    std::vector<bool> doneMask(ps.size(), false);
+    for (size_t a = 0; a < ps.size(); ++a) {
+        if (doneMask[a]) continue;
+        const int N = ps[a]->optData_.controlPoints.cols();
+        std::vector<size_t> idx;
+        for (size_t b = a; b < ps.size(); ++b)
+            if (!doneMask[b] && ps[b]->optData_.controlPoints.cols() == N && ps[b]->maxVel_ == ps[a]->maxVel_) {
+                idx.push_back(b);
+                doneMask[b] = true;
+            }
+        bsplineTraj* lead = ps[a];
+        if (N < 4 || N > VIGO_MAX_CTRL_POINTS || !lead->syncDevice()) continue;
+        std::vector<double> ctrl, obs;
+        std::vector<int32_t> ooff{0};
+        for (size_t b : idx) {
+            const double* c = ps[b]->optData_.controlPoints.data();
+            ctrl.insert(ctrl.end(), c, c + 3 * N);
+            for (size_t j = 0; j < ps[b]->optData_.dynamicObstaclesPos.size(); ++j) {
+                for (int q = 0; q < 3; ++q) obs.push_back(ps[b]->optData_.dynamicObstaclesPos[j](q));
+                for (int q = 0; q < 3; ++q) obs.push_back(ps[b]->optData_.dynamicObstaclesVel[j](q));
+                for (int q = 0; q < 3; ++q) obs.push_back(ps[b]->optData_.dynamicObstaclesSize[j](q));
+            }
+            ooff.push_back((int32_t)(obs.size() / 9));
+        }
+        const int B = (int)idx.size();
+        DevBuf dCtrl, dFlag, dDyn, dOoff, dObs;
+        if (!dCtrl.upload(ctrl.data(), ctrl.size() * 8) || !dFlag.alloc(B) || !dDyn.alloc(B) ||
+            !dOoff.upload(ooff.data(), ooff.size() * 4) || !dObs.upload(obs.data(), obs.size() * 8))
+            continue;
+        const double dt = lead->map_->getRes() / lead->maxVel_ / 2.0;  // BT.h:312
+        if (vigo_traj_collision(lead->dev_, B, N, (const double*)dCtrl.p, dt, (uint8_t*)dFlag.p, nullptr) != VIGO_OK) continue;
+        std::vector<uint8_t> f(B), d(B, 0);
+        if (!obs.empty()) {
+            if (vigo_traj_dynamic_collision(lead->dev_, B, N, (const double*)dCtrl.p, dt, (const int32_t*)dOoff.p,
+                                            (const double*)dObs.p, 0, (uint8_t*)dDyn.p) != VIGO_OK)
+                continue;
+        }
+        if (hipDeviceSynchronize() != hipSuccess || !dFlag.download(f.data(), B)) continue;
+        if (!obs.empty() && !dDyn.download(d.data(), B)) continue;
+        for (int b = 0; b < B; ++b) {
+            col[idx[b]] = f[b];
+            // BT.cpp:621-626: the dynamic gate only runs when the planner has obstacles
+            dyn[idx[b]] = ps[idx[b]]->optData_.dynamicObstaclesPos.empty() ? 0 : d[b];
+        }
+    }
+}
+
+// BT.cpp:687-718
+int bsplineTraj::optimize() {
+    std::vector<bsplineTraj*> one{this};
+    solveBatch(one);
+    return lastStatus_;
+}
+
+// the lbfgs_evaluate_t seam on the device (BT.cpp:796-821)
+double bsplineTraj::costFunction(const double* x, double* grad, const int n) {
+    const int N = optData_.controlPoints.cols();
+    if (n != 3 * (N - 2 * bsplineDegree) || !syncDevice()) return std::nan("");
+    std::memcpy(optData_.controlPoints.data() + 3 * bsplineDegree, x, n * sizeof(double));  // BT.cpp:803
+    std::vector<double> gpv, obs;
+    std::vector<int32_t> goff{0};
+    for (int i = 0; i < N; ++i) {
+        for (size_t j = 0; j < optData_.guidePoints[i].size(); ++j) {
+            for (int q = 0; q < 3; ++q) gpv.push_back(optData_.guidePoints[i][j](q));
+            for (int q = 0; q < 3; ++q) gpv.push_back(optData_.guideDirections[i][j](q));
+        }
+        goff.push_back((int32_t)(gpv.size() / 6));
+    }
+    for (size_t j = 0; j < optData_.dynamicObstaclesPos.size(); ++j) {
+        for (int q = 0; q < 3; ++q) obs.push_back(optData_.dynamicObstaclesPos[j](q));
+        for (int q = 0; q < 3; ++q) obs.push_back(optData_.dynamicObstaclesVel[j](q));
+        for (int q = 0; q < 3; ++q) obs.push_back(optData_.dynamicObstaclesSize[j](q));
+    }
+    const size_t G = gpv.size() / 6;
+    DevBuf dCtrl, dGoff, dGpv, dGunk, dObs, dCost, dGrad;
+    if (!dCtrl.upload(optData_.controlPoints.data(), 3 * N * 8) || !dGoff.upload(goff.data(), goff.size() * 4) ||
+        !dGpv.upload(gpv.data(), gpv.size() * 8) || !dGunk.alloc(G) || !dObs.upload(obs.data(), obs.size() * 8) ||
+        !dCost.alloc(8) || !dGrad.alloc((size_t)n * 8))
+        return std::nan("");
+    if (G && vigo_guides_unknown(dev_, (int64_t)G, (const double*)dGpv.p, (uint8_t*)dGunk.p) != VIGO_OK) return std::nan("");
+    if (vigo_cost_grad(dev_, 1, N, (const double*)dCtrl.p, (const int32_t*)dGoff.p, G ? (const double*)dGpv.p : nullptr,
+                       G ? (const uint8_t*)dGunk.p : nullptr, nullptr, obs.empty() ? nullptr : (const double*)dObs.p,
+                       (int)(obs.size() / 9), nullptr, (double*)dCost.p, (double*)dGrad.p, nullptr) != VIGO_OK)
+        return std::nan("");
+    double cost = 0;
+    if (hipDeviceSynchronize() != hipSuccess || !dCost.download(&cost, 8) || !dGrad.download(grad, (size_t)n * 8)) return std::nan("");
+    return cost;
+}
+
+// BT.h:307-325 / :344-368 through the device gates
+bool bsplineTraj::hasCollisionTrajectory(const Eigen::MatrixXd& controlPoints) {
+    Eigen::MatrixXd keep = optData_.controlPoints;
+    optData_.controlPoints = controlPoints;
+    std::vector<bsplineTraj*> one{this};
+    std::vector<uint8_t> col, dyn;
+    gateBatch(one, col, dyn);
+    optData_.controlPoints = keep;
+    return col[0] != 0;
+}
+
+bool bsplineTraj::hasDynamicCollisionTrajectory(const Eigen::MatrixXd& controlPoints) {
+    Eigen::MatrixXd keep = optData_.controlPoints;
+    optData_.controlPoints = controlPoints;
+    std::vector<bsplineTraj*> one{this};
+    std::vector<uint8_t> col, dyn;
+    gateBatch(one, col, dyn);
+    optData_.controlPoints = keep;
+    return dyn[0] != 0;
+}
+
+void bsplineTraj::reboundBegin(Rebound& r) {
+    r = Rebound();
+    r.w0 = this->weightDistance_;
+    r.wo0 = this->weightDynamicObstacle_;
+}
+
+// the body of the while loop of BT.cpp:619-681, one pass
+void bsplineTraj::reboundStep(Rebound& r, bool hasCollision, bool hasDynamicCollision, bool timedOut) {
+    r.needOptimize = false;
+    auto finish = [&](bool ok) {
+        this->weightDistance_ = r.w0;
+        this->weightDynamicObstacle_ = r.wo0;
+        r.done = true;
+        r.ok = ok;
+    };
+    if (!hasCollision && !hasDynamicCollision) { finish(true); return; }
+    if (timedOut) { cout << "[BsplineTraj]: Optimization timeout." << endl; finish(false); return; }
+    std::vector<std::vector<Eigen::Vector3d>> tempAstarPaths;
+    if (r.failCount >= 4) {
+        std::vector<std::pair<int, int>> collisionSeg;
+        this->findCollisionSeg(this->optData_.controlPoints, collisionSeg);
+        if (this->pathSearch(collisionSeg, tempAstarPaths)) {
+            this->astarPaths_ = tempAstarPaths;
+            this->assignGuidePointsSemiCircle(tempAstarPaths, collisionSeg);
+        }
+    }
+    if (r.failCount >= 8) { finish(false); return; }
+    if (hasCollision) {
+        std::vector<std::pair<int, int>> reguideCollisionSeg;
+        if (this->isReguideRequired(reguideCollisionSeg)) {
+            if (this->pathSearch(reguideCollisionSeg, tempAstarPaths)) {
+                this->astarPaths_ = tempAstarPaths;
+                this->assignGuidePointsSemiCircle(tempAstarPaths, reguideCollisionSeg);
+            } else {
+                this->weightDistance_ *= 2.0;
+                ++r.failCount;
+            }
+        } else {
+            this->weightDistance_ *= 2.0;
+            ++r.failCount;
+        }
+    }
+    if (hasDynamicCollision) this->weightDynamicObstacle_ *= 2.0;
+    r.needOptimize = true;
+}
+
+// BT.cpp:611-685 for one planner
+bool bsplineTraj::optimizeTrajectory() {
+    std::vector<bsplineTraj*> one{this};
+    // makePlanBatch's inner loop without the A* prologue
+    Rebound r;
+    reboundBegin(r);
+    solveBatch(one);
+    const double t0 = wallSeconds();
+    while (!r.done) {
+        std::vector<uint8_t> col, dyn;
+        gateBatch(one, col, dyn);
+        reboundStep(r, col[0] != 0, dyn[0] != 0, wallSeconds() - t0 > 0.03);
+        if (!r.done && r.needOptimize) solveBatch(one);
+    }
+    return r.ok;
+}
+
+// BT.cpp:333-385 for many planners at once: host prologue per planner, then the rebound loops in
+// lock-step so each optimize() round is one launch over all still-active planners.
+std::vector<bool> bsplineTraj::makePlanBatch(const std::vector<bsplineTraj*>& planners) {
+    const size_t P = planners.size();
+    std::vector<bool> result(P, false);
+    std::vector<Rebound> rb(P);
+    std::vector<bsplineTraj*> active;
+    std::vector<size_t> activeIdx;
+    for (size_t i = 0; i < P; ++i) {
+        bsplineTraj* p = planners[i];
+        if (!p->init_ || !p->map_) continue;
+        p->findCollisionSeg(p->optData_.controlPoints, p->collisionSeg_);           // step 1
+        if (!p->pathSearch(p->collisionSeg_, p->astarPaths_)) {                     // step 2
+            cout << "[BsplineTraj]: Fail because of A* failure." << endl;
+            continue;
+        }
+        p->assignGuidePointsSemiCircle(p->astarPaths_, p->collisionSeg_);           // step 3
+        p->reboundBegin(rb[i]);
+        active.push_back(p);
+        activeIdx.push_back(i);
+    }
+    // step 4: rebound loops.  The 30 ms budget of BT.cpp:633 is per makePlan() call in the
+    // reference; a batch keeps it per round so one slow planner cannot starve the others.
+    solveBatch(active);
+    const double t0 = wallSeconds();
+    const double budget = 0.03 * std::max<size_t>(1, active.size());
+    while (!active.empty()) {
+        std::vector<uint8_t> col, dyn;
+        gateBatch(active, col, dyn);
+        const bool timedOut = wallSeconds() - t0 > budget;
+        std::vector<bsplineTraj*> next, solve;
+        std::vector<size_t> nextIdx;
+        for (size_t a = 0; a < active.size(); ++a) {
+            Rebound& r = rb[activeIdx[a]];
+            active[a]->reboundStep(r, col[a] != 0, dyn[a] != 0, timedOut);
+            if (r.done) {
+                result[activeIdx[a]] = r.ok;
+                if (!r.ok) cout << "[BsplineTraj]: Fail because of optimizer not finding a solution." << endl;
+            } else {
+                next.push_back(active[a]);
+                nextIdx.push_back(activeIdx[a]);
+                if (r.needOptimize) solve.push_back(active[a]);
+            }
+        }
+        solveBatch(solve);
+        active.swap(next);
+        activeIdx.swap(nextIdx);
+    }
+    for (size_t i = 0; i < P; ++i) {
+        if (!result[i]) continue;
+        bsplineTraj* p = planners[i];
+        p->bspline_ = trajPlanner::bspline(bsplineDegree, p->optData_.controlPoints, p->controlPointsTs_);  // step 5
+        p->linearFeasibilityReparam();                                                                  // step 6
+    }
+    return result;
+}
+
+// BT.cpp:754-793 — including the function-static previous goal distance shared by all instances
+void bsplineTraj::adjustPathLengthDirect(const std::vector<Eigen::Vector3d>& path, std::vector<Eigen::Vector3d>& adjustedPath) {
+    static double prevPathLength = 0.0;
+    if (path.empty()) return;
+    double totalLength = 0.0;
+    bool exceedLength = false;
+    double minLength = 0.0;
+    Eigen::Vector3d pStart = path[0];
+    for (size_t i = 0; i + 1 < path.size(); ++i) {
+        Eigen::Vector3d p1 = path[i], p2 = path[i + 1];
+        totalLength = (p2 - pStart).norm();
+        if (totalLength >= std::max(prevPathLength, this->maxPathLength_)) exceedLength = true;
+        adjustedPath.push_back(p1);
+        if (exceedLength) {
+            bool free = !this->map_->isInflatedOccupiedLine(p1, p2);
+            if (free && minLength >= 1.5) {
+                adjustedPath.push_back(p2);
+                prevPathLength = totalLength;
+                return;
+            }
+        }
+        if (this->map_->isInflatedOccupiedLine(p1, p2)) minLength = 0.0;
+        else minLength += (p2 - p1).norm();
+    }
+    adjustedPath.push_back(path.back());
+    prevPathLength = totalLength;
+}
+
+// BT.cpp:1116-1137
+void bsplineTraj::linearFeasibilityReparam() {
+    double trajMaxVel = 0.0, trajMaxAcc = 0.0;
+    trajPlanner::bspline trajVel = this->bspline_.getDerivative();
+    trajPlanner::bspline trajAcc = trajVel.getDerivative();
+    for (double t = 0.0; t < this->bspline_.getDuration(); t += this->ts_) {
+        trajMaxVel = std::max(trajMaxVel, trajVel.at(t).norm());
+        trajMaxAcc = std::max(trajMaxAcc, trajAcc.at(t).norm());
+    }
+    double factorVel = this->maxVel_ / trajMaxVel;
+    double factorAcc = std::sqrt(this->maxAcc_ / trajMaxAcc);
+    this->linearFactor_ = std::min(factorVel, factorAcc);
+}
+
+double bsplineTraj::getLinearReparamTime(double t) { return this->linearFactor_ * t; }
+double bsplineTraj::getLinearFactor() { return this->linearFactor_; }
+double bsplineTraj::getInitTs() { return this->controlPointDistance_ / this->maxVel_; }
+double bsplineTraj::getControlPointTs() { return this->controlPointsTs_; }
+double bsplineTraj::getControlPointDist() { return this->controlPointDistance_; }
+trajPlanner::bspline bsplineTraj::getTrajectory() { return this->bspline_; }
+
+// BT.cpp:1402-1419
+geometry_msgs::PoseStamped bsplineTraj::getPose(double t, bool yaw) {
+    geometry_msgs::PoseStamped ps;
+    Eigen::Vector3d p = this->bspline_.at(t);
+    ps.header.frame_id = "map";
+    ps.header.stamp = ros::Time::now();
+    ps.pose.position.x = p(0);
+    ps.pose.position.y = p(1);
+    ps.pose.position.z = p(2);
+    if (yaw) {
+        trajPlanner::bspline velBspline = this->bspline_.getDerivative();
+        Eigen::Vector3d vel = velBspline.at(t);
+        ps.pose.orientation = trajPlanner::quaternion_from_rpy(0, 0, std::atan2(vel(1), vel(0)));
+    }
+    return ps;
+}
+
+double bsplineTraj::getDuration() { return this->bspline_.getDuration(); }
+double bsplineTraj::getTimestep() { return this->ts_; }
+Eigen::MatrixXd bsplineTraj::getControlPoints() { return this->optData_.controlPoints; }
+
+std::vector<Eigen::Vector3d> bsplineTraj::evalTraj() { return this->evalTraj(this->map_->getRes() / this->maxVel_ / 2.0); }
+
+std::vector<Eigen::Vector3d> bsplineTraj::evalTraj(double dt) {
+    std::vector<Eigen::Vector3d> traj;
+    trajPlanner::bspline sp(bsplineDegree, this->optData_.controlPoints, this->controlPointsTs_);
+    for (double t = 0; t <= sp.getDuration(); t += dt) traj.push_back(sp.at(t));
+    return traj;
+}
+
+bool bsplineTraj::isCurrTrajValid() {
+    if (!this->init_) return false;
+    return !this->hasCollisionTrajectory(this->optData_.controlPoints);
+}
+
+// BT.h:327-342
+bool bsplineTraj::isCurrTrajValid(Eigen::Vector3d& firstCollisionPos) {
+    if (!this->init_) return false;
+    std::vector<Eigen::Vector3d> trajectory = this->evalTraj();
+    for (int i = 0; i < (1.0 - this->notCheckRatio_) * int(trajectory.size()); ++i) {
+        if (this->map_->isInflatedOccupied(trajectory[i])) {
+            firstCollisionPos = trajectory[i];
+            return false;
+        }
+    }
+    return true;
+}
+
+nav_msgs::Path bsplineTraj::evalTrajToMsg(bool yaw) { return this->evalTrajToMsg(this->ts_, yaw); }
+
+// BT.cpp:1502-1518
+nav_msgs::Path bsplineTraj::evalTrajToMsg(double dt, bool yaw) {
+    std::vector<Eigen::Vector3d> trajTemp = this->evalTraj(dt);
+    nav_msgs::Path traj;
+    this->eigenPointsToPathMsg(trajTemp, traj);
+    trajPlanner::bspline velBspline = this->bspline_.getDerivative();
+    for (size_t i = 0; i < traj.poses.size(); ++i) {
+        Eigen::Vector3d vel = velBspline.at((double)i * dt);
+        if (yaw) traj.poses[i].pose.orientation = trajPlanner::quaternion_from_rpy(0, 0, std::atan2(vel(1), vel(0)));
+    }
+    return traj;
+}
+
+void bsplineTraj::pathMsgToEigenPoints(const nav_msgs::Path& path, std::vector<Eigen::Vector3d>& points) {
+    for (const auto& ps : path.poses) points.push_back(Eigen::Vector3d(ps.pose.position.x, ps.pose.position.y, ps.pose.position.z));
+}
+
+void bsplineTraj::eigenPointsToPathMsg(const std::vector<Eigen::Vector3d>& points, nav_msgs::Path& path) {
+    path.poses.clear();
+    for (const auto& q : points) {
+        geometry_msgs::PoseStamped p;
+        p.pose.position.x = q(0);
+        p.pose.position.y = q(1);
+        p.pose.position.z = q(2);
+        path.poses.push_back(p);
+    }
+    path.header.frame_id = "map";
+}
+
+}  // namespace trajPlanner

@@ -1,0 +1,171 @@
+// test_facade.cpp — drives the C++ facades the way the reference's nodes drive the originals
+// (src/bspline_node.cpp:227-231, :344-378; src/poly_RRT_node.cpp:148-150).  Runs on the GPU box
+// (tests/test_gpu_facade.py); prints one "KEY value" line per check and exits non-zero on failure.
+#include <trajectory_planner/bsplineTraj.h>
+#include <trajectory_planner/polyTrajOctomap.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <set>
+
+using trajPlanner::bsplineTraj;
+
+static int fails = 0;
+#define CHECK(cond, msg) do { if (!(cond)) { std::printf("FAIL %s\n", msg); ++fails; } else std::printf("ok   %s\n", msg); } while (0)
+
+static std::shared_ptr<mapManager::occMap> makeMap() {
+    // 12.8 m cube at 0.1 m, origin on the key lattice; a wall with a gap and a pillar
+    auto m = std::make_shared<mapManager::occMap>(128, 128, 40, Eigen::Vector3d(-6.4, -6.4, -0.5), 0.1);
+    auto box = [&](double x0, double x1, double y0, double y1, double z0, double z1) {
+        for (int ix = 0; ix < 128; ++ix) for (int iy = 0; iy < 128; ++iy) for (int iz = 0; iz < 40; ++iz) {
+            const double x = -6.4 + (ix + 0.5) * 0.1, y = -6.4 + (iy + 0.5) * 0.1, z = -0.5 + (iz + 0.5) * 0.1;
+            if (x >= x0 && x <= x1 && y >= y0 && y <= y1 && z >= z0 && z <= z1) m->at(ix, iy, iz) |= 4;
+            if (x >= x0 - 0.4 && x <= x1 + 0.4 && y >= y0 - 0.4 && y <= y1 + 0.4 && z >= z0 - 0.15 && z <= z1 + 0.15) m->at(ix, iy, iz) |= 1;
+        }
+    };
+    box(-0.3, 0.3, -0.8, 0.8, -0.5, 3.5);   // pillar across the straight path
+    return m;
+}
+
+static ros::NodeHandle makeParams() {
+    ros::NodeHandle nh;   // cfg/bspline_interactive/bspline_planner_param.yaml
+    nh.setParam("bspline_traj/timestep", 0.1);
+    nh.setParam("bspline_traj/distance_threshold", 0.5);
+    nh.setParam("bspline_traj/distance_threshold_dynamic", 0.5);
+    nh.setParam("bspline_traj/weight_distance", 1.0);
+    nh.setParam("bspline_traj/weight_smoothness", 1.0);
+    nh.setParam("bspline_traj/weight_feasibility", 1.0);
+    nh.setParam("bspline_traj/weight_dynamic_obstacle", 1.0);
+    nh.setParam("bspline_traj/plan_in_z_axis", 0.0);
+    nh.setParam("bspline_traj/min_height", 0.7);
+    nh.setParam("bspline_traj/max_height", 1.3);
+    nh.setParam("bspline_traj/uncertain_aware_factor", 1.0);
+    nh.setParam("bspline_traj/max_path_length", 20.0);
+    nh.setParam("bspline_traj/max_obstacle_size", std::vector<double>{5, 5, 3});
+    nh.setParam("bspline_traj/prediction_horizon", 2.0);
+    return nh;
+}
+
+static nav_msgs::Path straight(double x0, double y0, double x1, double y1, double z, double spacing) {
+    nav_msgs::Path p;
+    const double len = std::hypot(x1 - x0, y1 - y0);
+    const int n = (int)(len / spacing);
+    for (int i = 0; i <= n; ++i) {
+        geometry_msgs::PoseStamped ps;
+        ps.pose.position.x = x0 + (x1 - x0) * i / n;
+        ps.pose.position.y = y0 + (y1 - y0) * i / n;
+        ps.pose.position.z = z;
+        p.poses.push_back(ps);
+    }
+    return p;
+}
+
+int main() {
+    auto map = makeMap();
+    const std::vector<Eigen::Vector3d> cond(4, Eigen::Vector3d(0, 0, 0));
+
+    // ---- single planner, the bspline_node.cpp sequence ----
+    bsplineTraj bst(makeParams());
+    bst.setMap(map);
+    bst.updateMaxVel(2.0);
+    bst.updateMaxAcc(3.0);
+    nav_msgs::Path path = straight(-3.0, 0.05, 3.0, 0.0, 1.0, bst.getControlPointDist());
+    CHECK(bst.updatePath(path, cond), "updatePath accepts a free goal");
+    Eigen::MatrixXd c0 = bst.getControlPoints();
+    CHECK(c0.cols() == (int)path.poses.size() + 2, "fit returns K+2 control points");
+    CHECK(bst.hasCollisionTrajectory(c0), "the straight path collides before planning (device gate)");
+    const bool ok = bst.makePlan();
+    CHECK(ok, "makePlan succeeds around the pillar");
+    Eigen::MatrixXd c1 = bst.getControlPoints();
+    CHECK(!bst.hasCollisionTrajectory(c1), "the planned trajectory is collision free (device gate)");
+    Eigen::Vector3d firstHit;
+    CHECK(bst.isCurrTrajValid(firstHit), "isCurrTrajValid (host evalTraj + map) agrees");
+    bool fixedKept = true;
+    for (int i = 0; i < 3; ++i) for (int a = 0; a < 3; ++a)
+        fixedKept = fixedKept && c0(a, i) == c1(a, i) && c0(a, c0.cols() - 1 - i) == c1(a, c1.cols() - 1 - i);
+    CHECK(fixedKept, "the first/last three control points are untouched (BT.cpp:690-691)");
+    CHECK(std::fabs(bst.getDuration() - (c1.cols() - 3) * 0.2) < 1e-12, "duration = (N-3) * controlPointsTs");
+    geometry_msgs::PoseStamped p0 = bst.getPose(0.0), pe = bst.getPose(bst.getDuration());
+    CHECK(std::fabs(p0.pose.position.x + 3.0) < 0.2 && std::fabs(pe.pose.position.x - 3.0) < 0.2, "getPose spans start to goal (least-squares fit, not interpolation)");
+    CHECK(std::fabs(p0.pose.orientation.w * p0.pose.orientation.w + p0.pose.orientation.z * p0.pose.orientation.z - 1.0) < 1e-12, "yaw-only unit quaternion");
+    CHECK(bst.getLinearFactor() > 0 && std::isfinite(bst.getLinearFactor()), "linear feasibility re-parameterisation factor");
+    std::printf("INFO solver status %d, linear factor %.4f\n", bst.getLastSolverStatus(), bst.getLinearFactor());
+
+    // the lbfgs_evaluate_t seam on the device: finite-difference check of costFunction
+    {
+        const int N = c1.cols(), n = 3 * (N - 6);
+        std::vector<double> x(c1.data() + 9, c1.data() + 9 + n), g(n), gp(n);
+        const double f0 = bst.costFunction(x.data(), g.data(), n);
+        double worst = 0;
+        for (int k = 0; k < n; k += 7) {
+            if (k % 3 == 2) continue;   // plan_in_z_axis = false zeroes the z gradient of the guide term by design
+            std::vector<double> xp = x, xm = x;
+            xp[k] += 1e-6; xm[k] -= 1e-6;
+            const double fd = (bst.costFunction(xp.data(), gp.data(), n) - bst.costFunction(xm.data(), gp.data(), n)) / 2e-6;
+            worst = std::fmax(worst, std::fabs(fd - g[k]) / std::fmax(1.0, std::fabs(g[k])));
+        }
+        CHECK(std::isfinite(f0) && worst < 1e-4, "costFunction gradient matches central differences");
+    }
+
+    // a goal inside an obstacle is refused (BT.cpp:291-295)
+    {
+        bsplineTraj b2(makeParams());
+        b2.setMap(map);
+        nav_msgs::Path bad = straight(-3.0, 0.0, 0.0, 0.0, 1.0, 0.25);
+        CHECK(!b2.updatePath(bad, cond), "updatePath refuses an occupied goal");
+    }
+
+    // ---- batch: 48 planners through ONE rebound loop ----
+    {
+        std::vector<std::unique_ptr<bsplineTraj>> owners;
+        std::vector<bsplineTraj*> ps;
+        for (int i = 0; i < 48; ++i) {
+            owners.emplace_back(new bsplineTraj(makeParams()));
+            bsplineTraj* b = owners.back().get();
+            b->setMap(map);
+            b->updateMaxVel(2.0);
+            b->updateMaxAcc(3.0);
+            const double y = -2.4 + 0.1 * i;   // some hit the pillar, some pass beside it
+            b->updatePath(straight(-3.0, y, 3.0, y + 0.03, 1.0, 0.25), cond);
+            ps.push_back(b);
+        }
+        std::vector<bool> res = bsplineTraj::makePlanBatch(ps);
+        int good = 0, clean = 0;
+        for (size_t i = 0; i < ps.size(); ++i) {
+            good += res[i];
+            if (res[i] && ps[i]->isCurrTrajValid()) ++clean;
+        }
+        std::printf("INFO batch: %d of %zu planned, %d verified collision free\n", good, ps.size(), clean);
+        CHECK(good >= 40 && clean == good, "makePlanBatch plans the batch and every success is collision free");
+    }
+
+    // ---- polyTrajOctomap checker ----
+    {
+        ros::NodeHandle nh;
+        nh.setParam("collision_box", std::vector<double>{0.4, 0.4, 0.2});
+        nh.setParam("map_resolution", 0.2);
+        nh.setParam("sample_delta_time", 0.1);
+        trajPlanner::polyTrajOctomap poly(nh);
+        poly.setMap(map);
+        std::vector<trajPlanner::pose> wp{{-3, 0, 1}, {0, 2.0, 1}, {3, 0, 1}};
+        poly.updatePath(wp);
+        // two degree-7 segments, linear in local time: through the pillar's side region then away
+        std::vector<double> xs(16, 0), ys(16, 0), zs(16, 0);
+        xs[0] = -3; xs[1] = 1.0; ys[0] = 0; ys[1] = 0.0; zs[0] = 1;          // segment 0: straight at y = 0 (hits the pillar)
+        xs[8] = 0; xs[9] = 1.0; ys[8] = 2.0; ys[9] = 0.0; zs[8] = 1;         // segment 1: y = 2 (free)
+        poly.setSolution(7, xs, ys, zs, {0.0, 3.0, 6.0});
+        std::vector<trajPlanner::pose> traj;
+        poly.makePlan(traj, 0.1);
+        std::set<int> seg;
+        const bool hit = poly.checkCollisionTraj(traj, 0.1, seg);
+        CHECK(hit && seg.count(0) == 1 && seg.count(1) == 0 && !poly.isValid(), "checkCollisionTraj blames segment 0 only");
+        CHECK(poly.checkCollision(trajPlanner::pose(0, 0, 1)) && !poly.checkCollision(trajPlanner::pose(-3, 0, 1)), "checkCollision box sweep");
+        CHECK(poly.checkCollisionPoint(trajPlanner::pose(0, 0, 1)) && !poly.checkCollisionPoint(trajPlanner::pose(0, 2, 1)), "checkCollisionPoint");
+        CHECK(std::fabs(poly.getDuration() - 6.0) < 1e-12 && std::fabs(poly.getPose(1.5).pose.position.x + 1.5) < 1e-12, "getDuration / getPose");
+    }
+
+    std::printf("%s (%d failures)\n", fails ? "FAILED" : "PASSED", fails);
+    return fails ? 1 : 0;
+}

@@ -276,6 +276,15 @@ class Vigo:
             C.c_void_p(count.data_ptr())), "vigo_corridor_check")
         return flag, first, count
 
+    def box_collision_points(self, pts, box, map_res):
+        """vigo_box_collision_points: pts [M,3] f64 -> uint8 [M]"""
+        M = pts.shape[0]
+        out = torch.empty(M, dtype=torch.uint8, device=self.device)
+        self._check(self._lib.vigo_box_collision_points(self._h, M, _ptr(pts, torch.float64, "pts", self.device),
+                                                        (C.c_double * 3)(*box), float(map_res),
+                                                        C.c_void_p(out.data_ptr())), "vigo_box_collision_points")
+        return out
+
     # ---- ESDF ---------------------------------------------------------------------------
     def set_esdf(self, dist: torch.Tensor, origin, res: float):
         nx, ny, nz = dist.shape
