@@ -1,0 +1,86 @@
+"""Measures the BASELINE.json configs 2-5 on one MI355X and prints one JSON line per config
+(run on the GPU box; the numbers feed profiles/README.md).  Parity for every kernel timed here is
+covered by tests/ -m gpu; this script only times."""
+import json, os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import numpy as np, torch
+from trajectory_planner_amd import synth
+from trajectory_planner_amd.vigo import PREC_F32, PREC_F64, Vigo, default_params
+
+dev = torch.device("cuda", 0)
+T = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def solve_cfg(name, world, B, N, prec, n_obs=0, reps=20):
+    b = synth.make_bspline_batch(world, B, N, 4242 + N + B, start_range=8.0 if N == 32 else 16.0, n_obs=n_obs)
+    P = default_params(); P.max_iterations = 50
+    v = Vigo(0, P, prec)
+    v.set_grid(T(world.voxels), world.origin, world.res)
+    ctrl, goff, gpv = T(b.ctrl), T(b.guide_off), T(b.guide_pv)
+    ooff, obs = T(b.obs_off), T(b.obs)
+    def step():
+        gunk = v.guides_unknown(gpv)
+        return v.optimize(ctrl, goff, gpv, gunk, ooff, obs)
+    dt = timeit(step, reps)
+    r = step()
+    print(json.dumps({"config": name, "B": B, "N": N, "precision": "f32" if prec == PREC_F32 else "f64", "obstacles_per_traj": n_obs,
+                      "ms_per_batch": dt * 1e3, "trajs_per_s": B / dt, "mean_evals": float(r.evals.float().mean()),
+                      "mean_iters": float(r.iters.float().mean())}), flush=True)
+    v.close()
+
+
+w256 = synth.make_box_world(synth.SEED_BASE + 2, n=256, n_boxes=200)
+solve_cfg("2: 1024x32, 256^3, 50 it", w256, 1024, 32, PREC_F64)
+solve_cfg("2 (fp32 mode)", w256, 1024, 32, PREC_F32)
+solve_cfg("2 at B=16384", w256, 16384, 32, PREC_F64, reps=5)
+solve_cfg("5a: dynamic-obstacle term, 8 obstacles/traj", w256, 1024, 32, PREC_F64, n_obs=8)
+
+# config 5b: 1 M trilinear ESDF queries per iteration
+n = 256
+dist, origin = synth.sphere_esdf(n, 0.1, (0.0, 0.0, 0.0), 5.0)
+v = Vigo(0)
+v.set_esdf(T(dist), origin, 0.1)
+rng = np.random.default_rng(5)
+pts = T(rng.uniform(-12.7, 12.7, size=(1 << 20, 3)))
+dt = timeit(lambda: v.esdf_query(pts), 50)
+print(json.dumps({"config": "5b: 1M trilinear ESDF queries (uniform random)", "ms": dt * 1e3, "queries_per_s": (1 << 20) / dt,
+                  "algorithmic_GBps": (1 << 20) * 60 / dt / 1e9}), flush=True)
+idx = np.lexsort(tuple(np.floor((pts.cpu().numpy()[:, a] + 12.8) / 0.8).astype(int) for a in (2, 1, 0)))
+pts_sorted = T(pts.cpu().numpy()[idx])
+dt = timeit(lambda: v.esdf_query(pts_sorted), 50)
+print(json.dumps({"config": "5b: same queries, brick-sorted", "ms": dt * 1e3, "queries_per_s": (1 << 20) / dt,
+                  "algorithmic_GBps": (1 << 20) * 60 / dt / 1e9}), flush=True)
+v.close()
+
+# config 3: 4096 segments x 10 000 samples corridor check on an occupied/free/unknown map
+rng = np.random.default_rng(3)
+vox = np.zeros((256, 256, 64), dtype=np.uint8)
+for _ in range(300):
+    c = rng.integers(8, 248, size=2); s = rng.integers(1, 6, size=2)
+    vox[c[0] - s[0]:c[0] + s[0], c[1] - s[1]:c[1] + s[1], 0:rng.integers(10, 64)] |= 4
+unk = rng.random((32, 32, 8)) < 0.05
+vox[np.repeat(np.repeat(np.repeat(unk, 8, 0), 8, 1), 8, 2)] |= 2
+world3 = synth.World(vox, np.array([-12.8, -12.8, -1.0]), 0.1, np.zeros((0, 6)))
+v = Vigo(0)
+v.set_grid(T(world3.voxels), world3.origin, world3.res)
+coeffs, n_samp, delT, dur = synth.make_corridor_segments(33, 4096, extent_lo=(-10, -10, 0.5), extent_hi=(10, 10, 2.5), n_samples=10000)
+c, ns, dl = T(coeffs), T(n_samp), T(delT)
+box = [0.4, 0.4, 0.2]
+dt = timeit(lambda: v.corridor_check(c, ns, dl, box, 0.2), 10, 2)
+flag, first, count = v.corridor_check(c, ns, dl, box, 0.2)
+samples = 4096 * 10000
+print(json.dumps({"config": "3: 4096 segments x 10k samples, box [0.4,0.4,0.2] step 0.2", "ms": dt * 1e3, "segments_per_s": 4096 / dt,
+                  "samples_per_s": samples / dt, "lattice_lookups_per_s": samples * 18 / dt, "colliding_segments": int(flag.sum())}), flush=True)
+v.close()
+
+# config 4 shard: 8192 x 64 control points, 512^3 grid
+w512 = synth.make_box_world(synth.SEED_BASE + 4, n=512, n_boxes=800, centre_range=24.0)
+solve_cfg("4 shard: 8192x64, 512^3, 50 it (one of 8 GPUs)", w512, 8192, 64, PREC_F64, reps=5)

@@ -25,6 +25,7 @@ namespace vigo {
 namespace {
 
 constexpr int kWave = 64;
+constexpr int kMaxMem = VIGO_MAX_MEM_SIZE;
 
 // reference status codes, LB:20-80
 enum : int {
@@ -60,11 +61,14 @@ enum : int {
 // ---- cross-lane primitives -----------------------------------------------------------
 
 // DPP wave shifts (GFX9 family): lane i receives lane i-1 (wave_shr:1) / i+1 (wave_shl:1).
+// Lane 0 (63) has no source and keeps an unspecified value: every consumer of a shifted value
+// is guarded by the control-point index, so the wave edges (and the seam between the two
+// 32-lane groups) are never read.
 __device__ __forceinline__ int dpp_prev_i32(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false);
+    return __builtin_amdgcn_mov_dpp(v, 0x138, 0xF, 0xF, false);
 }
 __device__ __forceinline__ int dpp_next_i32(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, false);
+    return __builtin_amdgcn_mov_dpp(v, 0x130, 0xF, 0xF, false);
 }
 __device__ __forceinline__ double from_prev(double v) {
     return __hiloint2double(dpp_prev_i32(__double2hiint(v)), dpp_prev_i32(__double2loint(v)));
@@ -210,13 +214,10 @@ template <typename T, int GROUP>
 __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LaneProblem<T>& Q, const T (&c)[3],
                                                  const T (&d)[3], T (&g)[3], double (&sums)[7]) {
     const int N = Q.N, p = Q.p;
-    // 7-point window c[p-3..p+3] by chained DPP shifts
-    T m1[3], m2[3], m3[3], p1[3], p2[3], p3[3];
+    // forward window c[p+1..p+3] by chained DPP shifts
+    T p1[3], p2[3], p3[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        m1[a] = from_prev(c[a]);
-        m2[a] = from_prev(m1[a]);
-        m3[a] = from_prev(m2[a]);
         p1[a] = from_next(c[a]);
         p2[a] = from_next(p1[a]);
         p3[a] = from_next(p2[a]);
@@ -225,27 +226,33 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
     T Gd[3] = {0, 0, 0}, Gs[3] = {0, 0, 0}, Gf[3] = {0, 0, 0}, Go[3] = {0, 0, 0};
     double part[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
-    // ---- smoothness, BT.cpp:934-950 (gather form of the scatter-add) ----
+    // Every lane evaluates the stencil term whose FIRST point it owns (index i = p): jerk_p,
+    // velocity_p, acceleration_p and their gradient magnitudes.  A control point's gradient is
+    // the reference's scatter-add seen from the receiving column: the terms of i = p-3..p, which
+    // are the SAME expressions evaluated by the lanes below, fetched with DPP shifts — identical
+    // bits, no recomputation (and half the fp64 divisions by ts).
+
+    // ---- smoothness, BT.cpp:934-950 ----
     {
-        T J0[3], J1[3], J2[3], J3[3];
+        T gt0[3];  // gradTemp = 2 * jerk_i, i = p
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            J0[a] = ((p3[a] - 3 * p2[a]) + 3 * p1[a]) - c[a];   // i = p
-            J1[a] = ((p2[a] - 3 * p1[a]) + 3 * c[a]) - m1[a];   // i = p-1
-            J2[a] = ((p1[a] - 3 * c[a]) + 3 * m1[a]) - m2[a];   // i = p-2
-            J3[a] = ((c[a] - 3 * m1[a]) + 3 * m2[a]) - m3[a];   // i = p-3
+            const T J0 = ((p3[a] - 3 * p2[a]) + 3 * p1[a]) - c[a];
+            gt0[a] = T(2.0) * J0;
+            Gs[a] = J0;  // parked for the cost below
         }
         if (Q.has_pt && p <= N - 4)
-            part[1] = sum3((double)(J0[0] * J0[0]), (double)(J0[1] * J0[1]), (double)(J0[2] * J0[2]));
-        if (Q.interior) {
+            part[1] = sum3((double)(Gs[0] * Gs[0]), (double)(Gs[1] * Gs[1]), (double)(Gs[2] * Gs[2]));
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                T acc = T(2.0) * J3[a];             // i=p-3: col(i+3) += gradTemp
-                acc += T(-3.0) * (T(2.0) * J2[a]);  // i=p-2: col(i+2) += -3*gradTemp
-                acc += T(3.0) * (T(2.0) * J1[a]);   // i=p-1: col(i+1) += 3*gradTemp
-                acc += -(T(2.0) * J0[a]);           // i=p  : col(i)   += -gradTemp
-                Gs[a] = acc;
-            }
+        for (int a = 0; a < 3; ++a) {
+            const T gt1 = from_prev(gt0[a]);   // i = p-1
+            const T gt2 = from_prev(gt1);      // i = p-2
+            const T gt3 = from_prev(gt2);      // i = p-3
+            T acc = gt3;                       // i=p-3: col(i+3) += gradTemp
+            acc += T(-3.0) * gt2;              // i=p-2: col(i+2) += -3*gradTemp
+            acc += T(3.0) * gt1;               // i=p-1: col(i+1) += 3*gradTemp
+            acc += -gt0[a];                    // i=p  : col(i)   += -gradTemp
+            Gs[a] = acc;
         }
     }
 
@@ -253,33 +260,31 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
     {
         const T ts = (T)K.ts_ctrl, tis = (T)K.ts_inv_sqr;
         auto excess = [](T v) -> T { return v > T(1.0) ? v - T(1.0) : (v < T(-1.0) ? v + T(1.0) : T(0.0)); };
-        T evP[3], eaP[3];
+        double cfv = 0.0, ea2[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            evP[a] = excess((p1[a] - c[a]) / ts);                        // velocity i = p
-            eaP[a] = excess(((p2[a] - 2 * p1[a]) + c[a]) * tis);         // acc i = p
-            const T evM = excess((c[a] - m1[a]) / ts);                   // velocity i = p-1
-            const T eaM1 = excess(((p1[a] - 2 * c[a]) + m1[a]) * tis);   // acc i = p-1
-            const T eaM2 = excess(((c[a] - 2 * m1[a]) + m2[a]) * tis);   // acc i = p-2
-            if (Q.interior) {
-                T acc = (T(2) * evM) / ts * tis;       // i=p-1: gradient(j,i+1)
-                acc += (T(-2) * evP[a]) / ts * tis;    // i=p  : gradient(j,i)
-                acc += (T(2) * eaM2) * tis;            // i=p-2: gradient(j,i+2)
-                acc += (T(-4) * eaM1) * tis;           // i=p-1: gradient(j,i+1)
-                acc += (T(2) * eaP[a]) * tis;          // i=p  : gradient(j,i)
-                Gf[a] = acc;
-            }
+            const T evP = excess((p1[a] - c[a]) / ts);                   // velocity i = p
+            const T eaP = excess(((p2[a] - 2 * p1[a]) + c[a]) * tis);    // acceleration i = p
+            // gradient(j,i+1) += 2(v-vmax)/ts*tsInvSqr, gradient(j,i) += the negation (exactly)
+            const T gv = (T(2) * evP) / ts * tis;
+            // gradient(j,i) and (j,i+2) += 2(a-amax)*tsInvSqr, gradient(j,i+1) += -4(...) = -2x that (exactly)
+            const T ga = (T(2) * eaP) * tis;
+            const T gvM = from_prev(gv);       // velocity i = p-1
+            const T gaM1 = from_prev(ga);      // acceleration i = p-1
+            const T gaM2 = from_prev(gaM1);    // acceleration i = p-2
+            T acc = gvM;                       // i=p-1: gradient(j,i+1)
+            acc += -gv;                        // i=p  : gradient(j,i)
+            acc += gaM2;                       // i=p-2: gradient(j,i+2)
+            acc += -(T(2) * gaM1);             // i=p-1: gradient(j,i+1)
+            acc += ga;                         // i=p  : gradient(j,i)
+            Gf[a] = acc;
+            cfv += (double)((evP * evP) * tis);
+            ea2[a] = (double)(eaP * eaP);
         }
         // cost partial of lane p: velocity i=p (x,y,z) then acceleration i=p (x,y,z)
         double cf = 0.0;
-        if (Q.has_pt && p <= N - 2) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) cf += (double)((evP[a] * evP[a]) * tis);
-        }
-        if (Q.has_pt && p <= N - 3) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) cf += (double)(eaP[a] * eaP[a]);
-        }
+        if (Q.has_pt && p <= N - 2) cf = cfv;
+        if (Q.has_pt && p <= N - 3) { cf += ea2[0]; cf += ea2[1]; cf += ea2[2]; }
         part[2] = cf;
     }
 
@@ -573,7 +578,6 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
     const int m = K.mem_size;
     HPair<T>* hist = reinterpret_cast<HPair<T>*>(lds_raw);
     double* ys_tab = reinterpret_cast<double*>(lds_raw + (((size_t)m * ROW * sizeof(HPair<T>) + 15) & ~(size_t)15));
-    double* alpha_tab = ys_tab + (size_t)m * TPB;
 
     const int lane = threadIdx.x;
     const int grp = lane / GROUP;
@@ -588,7 +592,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
     const int pc = (p < 3) ? 3 : ((p > N - 4) ? N - 4 : p);
     HPair<T>* hl = hist + (grp * NI + (pc - 3));
     double* ys_l = ys_tab + grp;
-    double* al_l = alpha_tab + grp;
+    double* al_l = ys_tab + (size_t)m * TPB + grp;
 
     // x holds this lane's control point: a free variable on interior lanes, a fixed boundary
     // point elsewhere (its g, d, s, y are identically zero so it never moves).
@@ -733,76 +737,67 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
         const double ys = ysyy[0], yy = ysyy[1];
         ys_l[end * TPB] = ys;
 
-        // two-loop recursion, LB:1286-1316.  Rolled, unrolled by two with ping-pong register sets
-        // (A, B): while one history pair is being reduced the next one is already in flight from
-        // LDS, and nothing is copied between steps.
+        // two-loop recursion, LB:1286-1316, fully unrolled over the pair's age with a register
+        // window of kWin pairs (static index age % kWin): the pair needed kWin steps ahead is
+        // fetched from LDS into the window slot the current step has just consumed, so the
+        // dependent chain never waits for LDS and does no address arithmetic or copies.
         const int bound = (m <= k) ? m : k;
         ++k;
-        int j = end;                                   // slot of the pair just stored (age 0)
+        const int newest = end;                        // slot of the pair just stored (age 0)
         end = (end + 1 == m) ? 0 : end + 1;
 #pragma unroll
         for (int a = 0; a < 3; ++a) d[a] = -g[a];
 
-        T sA[3] = {sv[0], sv[1], sv[2]}, yA[3] = {yv[0], yv[1], yv[2]}, sB[3], yB[3];
-        double ysA = ys, ysB = 0.0;
-        auto fetch = [&](int slot, T (&s_)[3], T (&y_)[3], double& ys_) {
+#ifndef VIGO_TWOLOOP_WIN
+#define VIGO_TWOLOOP_WIN 2
+#endif
+        constexpr int kWin = VIGO_TWOLOOP_WIN;
+        T Ps[kWin][3], Py[kWin][3];
+        double Pys[kWin];
+        auto fetch = [&](int age, T (&s_)[3], T (&y_)[3], double& ys_) {
+            int slot = newest - age;
+            if (slot < 0) slot += m;
             const HPair<T> h = hl[slot * ROW];
 #pragma unroll
             for (int a = 0; a < 3; ++a) { s_[a] = h.s[a]; y_[a] = h.y[a]; }
             ys_ = ys_l[slot * TPB];
         };
-        auto older = [m](int slot) { return slot == 0 ? m - 1 : slot - 1; };
-        auto newer = [m](int slot) { return slot + 1 == m ? 0 : slot + 1; };
-        // LB:1294-1303: alpha_j = (s_j . q) / ys_j ; q -= alpha_j y_j
-        auto down = [&](const T (&s_)[3], const T (&y_)[3], double ys_, int age) {
-            double al = group_sum1<GROUP>(dot3(s_, d));
-            al /= ys_;
-            al_l[age * TPB] = al;
-            const T na = Q.interior ? (T)(-al) : T(0);
 #pragma unroll
-            for (int a = 0; a < 3; ++a) d[a] += na * y_[a];
-        };
-        // LB:1307-1316: beta = (y_j . r) / ys_j ; r += (alpha_j - beta) s_j
-        auto up = [&](const T (&s_)[3], const T (&y_)[3], double ys_, int age) {
-            double beta = group_sum1<GROUP>(dot3(y_, d));
-            beta /= ys_;
-            const T co = Q.interior ? (T)(al_l[age * TPB] - beta) : T(0);
+        for (int a = 0; a < 3; ++a) { Ps[0][a] = sv[a]; Py[0][a] = yv[a]; }
+        Pys[0] = ys;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) d[a] += co * s_[a];
-        };
-
-        bool oldest_in_b = false;
-        for (int age = 0; age < bound; age += 2) {  // newest -> oldest
-            const int jb = older(j);
-            if (age + 1 < bound) fetch(jb, sB, yB, ysB);
-            down(sA, yA, ysA, age);
-            if (age + 1 >= bound) break;
-            const int ja = older(jb);
-            if (age + 2 < bound) fetch(ja, sA, yA, ysA);
-            down(sB, yB, ysB, age + 1);
-            if (age + 2 >= bound) { oldest_in_b = true; j = jb; break; }
-            j = ja;
-        }
-        if (oldest_in_b) {
+        for (int age = 1; age < kWin; ++age)
+            if (age < bound) fetch(age, Ps[age], Py[age], Pys[age]);
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { sA[a] = sB[a]; yA[a] = yB[a]; }
-            ysA = ysB;
+        for (int age = 0; age < kMaxMem; ++age) {      // newest -> oldest, LB:1294-1303
+            if (age < bound) {
+                const int w = age % kWin;
+                double al = group_sum1<GROUP>(dot3(Ps[w], d));
+                al /= Pys[w];
+                al_l[age * TPB] = al;      // alpha_j parks in LDS at a static offset
+                const T na = Q.interior ? (T)(-al) : T(0);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) d[a] += na * Py[w][a];
+                if (age + kWin < kMaxMem && age + kWin < bound) fetch(age + kWin, Ps[w], Py[w], Pys[w]);
+            }
         }
         {
             const T sc = (T)(ys / yy);  // LB:1305
 #pragma unroll
             for (int a = 0; a < 3; ++a) d[a] *= sc;
         }
-        // set A holds the oldest pair (slot j)
-        for (int age = bound - 1; age >= 0; age -= 2) {  // oldest -> newest
-            const int jb = newer(j);
-            if (age >= 1) fetch(jb, sB, yB, ysB);
-            up(sA, yA, ysA, age);
-            if (age < 1) break;
-            const int ja = newer(jb);
-            if (age >= 2) fetch(ja, sA, yA, ysA);
-            up(sB, yB, ysB, age - 1);
-            j = ja;
+        // the window now holds the ages [max(0, bound - kWin), bound)
+#pragma unroll
+        for (int age = kMaxMem - 1; age >= 0; --age) {  // oldest -> newest, LB:1307-1316
+            if (age < bound) {
+                const int w = age % kWin;
+                double beta = group_sum1<GROUP>(dot3(Py[w], d));
+                beta /= Pys[w];
+                const T co = Q.interior ? (T)(al_l[age * TPB] - beta) : T(0);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) d[a] += co * Ps[w][a];
+                if (age - kWin >= 0) fetch(age - kWin, Ps[w], Py[w], Pys[w]);
+            }
         }
         sums[4] = group_sum1<GROUP>(dot3(g, d));  // dginit of the next line search (LB:746)
         step = 1.0;  // LB:1321
