@@ -57,7 +57,9 @@ typedef enum {
     VIGO_ERR_UNSUPPORTED = -6    /* parameter combination not implemented             */
 } vigo_status_t;
 
-enum { VIGO_MAX_CTRL_POINTS = 64, VIGO_MAX_MEM_SIZE = 16 };
+/* vigo_optimize additionally needs mem_size * (N-6) * 48 B (fp64) of LDS <= 160 KiB:
+ * N <= 219 at mem_size 16; larger N returns VIGO_ERR_UNSUPPORTED_N. */
+enum { VIGO_MAX_CTRL_POINTS = 256, VIGO_MAX_MEM_SIZE = 16 };
 
 /* arithmetic mode of the solver / cost kernels */
 typedef enum {

@@ -27,17 +27,24 @@
 /*            (rounding-level) differences do to a 50-iteration solve.                      */
 /* ------------------------------------------------------------------------------------ */
 static int g_emu_group = 0;
-void vgo_set_emulation(int group) { g_emu_group = group; }
+static int g_emu_ppl = 1;   /* consecutive control points owned by one lane */
+void vgo_set_emulation(int group) { g_emu_group = group; g_emu_ppl = 1; }
+void vgo_set_emulation2(int group, int ppl) { g_emu_group = group; g_emu_ppl = ppl > 0 ? ppl : 1; }
 int vgo_get_emulation(void) { return g_emu_group; }
 
 static inline double P2(double x) { return g_emu_group ? x * x : pow(x, 2); }
 static inline double P3(double x) { return g_emu_group ? (x * x) * x : pow(x, 3); }
 static inline double PHALF(double x) { return g_emu_group ? sqrt(x) : pow(x, 0.5); }
 
-/* butterfly all-reduce of per-lane partials (lanes[GROUP]); returns lane 0's value */
-static double lane_tree_sum(const double* lanes, int group) {
+/* per-point partials pts[group*ppl] -> lane partial (the lane's points in index order, starting
+ * from 0.0) -> butterfly all-reduce; returns lane 0's value */
+static double lane_tree_sum(const double* pts, int group) {
     double a[64], b[64];
-    for (int i = 0; i < group; ++i) a[i] = lanes[i];
+    for (int i = 0; i < group; ++i) {
+        double s = 0.0;
+        for (int q = 0; q < g_emu_ppl; ++q) s += pts[i * g_emu_ppl + q];
+        a[i] = s;
+    }
     for (int m = 1; m < group; m <<= 1) {
         for (int i = 0; i < group; ++i) b[i] = a[i] + a[i ^ m];
         for (int i = 0; i < group; ++i) a[i] = b[i];
@@ -324,7 +331,7 @@ double vgo_cost_grad(const vigo_params_t* P, int N, const double* ctrl, const in
     memset(Gs, 0, sizeof(double) * 3 * N);
     memset(Gf, 0, sizeof(double) * 3 * N);
     memset(Go, 0, sizeof(double) * 3 * N);
-    double L[4][64];
+    double L[4][VGO_MAX_N];   /* per-point cost partials (device emulation) */
     memset(L, 0, sizeof(L));
     const int emu = g_emu_group != 0;
     double cd = distance_term(P, N, ctrl, goff, gpv, gunk, Gd, emu ? L[0] : NULL);
@@ -357,12 +364,12 @@ enum {
 
 static double dotn(const double* a, const double* b, int n) {
     if (g_emu_group) {
-        /* device emulation: lane p = control point p owns elements 3(p-3)..3(p-3)+2 */
-        double lanes[64];
-        memset(lanes, 0, sizeof(lanes));
+        /* device emulation: control point p owns elements 3(p-3)..3(p-3)+2 */
+        double pts[VIGO_MAX_CTRL_POINTS];
+        memset(pts, 0, sizeof(pts));
         for (int i = 0; i < n / 3; ++i)
-            lanes[i + 3] = sum3(a[3 * i] * b[3 * i], a[3 * i + 1] * b[3 * i + 1], a[3 * i + 2] * b[3 * i + 2]);
-        return lane_tree_sum(lanes, g_emu_group);
+            pts[i + 3] = sum3(a[3 * i] * b[3 * i], a[3 * i + 1] * b[3 * i + 1], a[3 * i + 2] * b[3 * i + 2]);
+        return lane_tree_sum(pts, g_emu_group);
     }
     double s = 0.;
     for (int i = 0; i < n; ++i) s += a[i] * b[i];

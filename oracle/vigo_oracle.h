@@ -35,6 +35,7 @@ void vgo_default_params(vigo_params_t* p);
 /* 0 = reference order (default); 32 / 64 = emulate the HIP kernels' lane-tree sums and
  * pow-free powers so results can be compared with the GPU bit for bit (vigo_oracle.c top). */
 void vgo_set_emulation(int group);
+void vgo_set_emulation2(int group, int points_per_lane);
 int vgo_get_emulation(void);
 
 /* dense voxel map, same contract as vigo_set_grid (include/vigo.h) */

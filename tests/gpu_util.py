@@ -25,10 +25,10 @@ class emulation:
     """context manager: oracle in device-emulation mode for N control points"""
 
     def __init__(self, N):
-        self.g = ol.emulation_group(N)
+        self.g, self.ppl = ol.emulation_shape(N)
 
     def __enter__(self):
-        ol.set_emulation(self.g)
+        ol.set_emulation(self.g, self.ppl)
 
     def __exit__(self, *a):
         ol.set_emulation(0)

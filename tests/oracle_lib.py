@@ -45,6 +45,7 @@ def oracle():
         L = C.CDLL(ORACLE_SO)
         L.vgo_default_params.argtypes = [C.POINTER(VigoParams)]
         L.vgo_set_emulation.argtypes = [C.c_int]
+        L.vgo_set_emulation2.argtypes = [C.c_int, C.c_int]
         L.vgo_get_emulation.restype = C.c_int
         L.vgo_cost_grad.restype = C.c_double
         L.vgo_cost_grad.argtypes = [C.POINTER(VigoParams), C.c_int, _dp, _ip, _dp, _up, C.c_int, _dp, _dp, _dp, _dp, _dp]
@@ -105,12 +106,21 @@ def default_params() -> VigoParams:
     return p
 
 
-def set_emulation(group: int):
-    oracle().vgo_set_emulation(int(group))
+def set_emulation(group: int, ppl: int = 1):
+    oracle().vgo_set_emulation2(int(group), int(ppl))
 
 
 def emulation_group(N: int) -> int:
     return 32 if N <= 32 else 64
+
+
+def emulation_shape(N: int):
+    """(lanes per trajectory, control points per lane) the HIP kernels use for N control points"""
+    if N <= 32:
+        return 32, 1
+    if N <= 64:
+        return 64, 1
+    return (64, 2) if N <= 128 else (64, 4)
 
 
 def _d(a):

@@ -30,7 +30,8 @@ def solve_both(v, P, b, weights=None):
 
 
 @pytest.mark.parametrize("N,B,n_obs,iters", [(32, 257, 0, 50), (32, 64, 2, 200), (7, 33, 0, 50), (12, 50, 1, 50),
-                                             (33, 40, 0, 50), (64, 65, 2, 50), (50, 31, 0, 50)])
+                                             (33, 40, 0, 50), (64, 65, 2, 50), (50, 31, 0, 50),
+                                             (65, 9, 0, 50), (82, 20, 1, 50), (128, 6, 0, 50), (129, 5, 1, 50), (200, 3, 0, 50)])
 def test_optimize_matches_oracle(vigo_handle, small_world, N, B, n_obs, iters):
     v = vigo_handle
     P = default_params()
@@ -62,7 +63,7 @@ def test_optimize_matches_oracle(vigo_handle, small_world, N, B, n_obs, iters):
 
 def test_cost_grad_matches_oracle_all_terms(vigo_handle, small_world):
     v = vigo_handle
-    for (N, n_obs, planz, unc) in [(32, 2, 0, 1.0), (20, 3, 1, 2.0), (64, 1, 0, 2.0), (9, 0, 1, 1.0)]:
+    for (N, n_obs, planz, unc) in [(32, 2, 0, 1.0), (20, 3, 1, 2.0), (64, 1, 0, 2.0), (9, 0, 1, 1.0), (100, 2, 1, 2.0), (256, 1, 0, 1.0)]:
         P = default_params()
         P.plan_in_z, P.uncertain_factor = planz, unc
         v.set_params(P)
@@ -129,7 +130,9 @@ def test_edge_cases(vigo_handle, small_world):
     with pytest.raises(VigoError):
         v.optimize(torch.zeros(1, 6, 3, dtype=torch.float64, device=dev))
     with pytest.raises(VigoError):
-        v.optimize(torch.zeros(1, 65, 3, dtype=torch.float64, device=dev))
+        v.optimize(torch.zeros(1, 257, 3, dtype=torch.float64, device=dev))     # > VIGO_MAX_CTRL_POINTS
+    with pytest.raises(VigoError):
+        v.optimize(torch.zeros(1, 230, 3, dtype=torch.float64, device=dev))     # history does not fit 160 KiB of LDS
     # max_iterations = 1 and mem_size = 3 (history ring wraps many times)
     for (iters, mem) in ((1, 16), (50, 3), (50, 1)):
         P2 = default_params()

@@ -302,6 +302,8 @@ int vigo_optimize(vigo_handle_t h, int B, int N, double* ctrl, const int32_t* gu
     a.weights = weights;
     a.out_x = out_x; a.out_status = out_status; a.out_fx = out_fx;
     a.out_iters = out_iters; a.out_evals = out_evals;
+    if (vigo::optimize_lds_requirement(N, h->params.mem_size, h->precision) > (size_t)160 * 1024)
+        return fail(h, VIGO_ERR_UNSUPPORTED_N, "the L-BFGS history of N control points x mem_size does not fit the 160 KiB LDS of a CU");
     VIGO_HIP(h, (hipError_t)vigo::launch_optimize(h->stream, a, h->dc, h->precision));
     return VIGO_OK;
 }

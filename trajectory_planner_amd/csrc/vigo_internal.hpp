@@ -77,6 +77,8 @@ struct EsdfView {
 // launchers (each returns hipError_t as int)
 int launch_cost_grad(hipStream_t s, const SolveArgs& a, const DevConst& k, int precision);
 int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, int precision);
+// LDS bytes one solve workgroup needs for N control points (must stay <= 160 KiB)
+size_t optimize_lds_requirement(int N, int mem_size, int precision);
 
 int launch_pack_grid(hipStream_t s, int nx, int ny, int nz, const uint8_t* vox, uint32_t* packed);
 int launch_query_points(hipStream_t s, const GridView& g, int which, int64_t Q, const double* pts,

@@ -1,18 +1,19 @@
 // vigo_solver.hip — batched ViGO cost/gradient and the whole-solve L-BFGS kernel for gfx950.
 //
 // Mapping (MI355X-first, no MFMA: there is no dense contraction on this path):
-//   * one 64-lane wavefront per workgroup; a trajectory owns a lane GROUP of 32 (N <= 32,
-//     two trajectories per wave) or 64 lanes (N <= 64); lane p <-> control point p, so the
-//     4-point jerk stencil and the 2/3-point vel/acc stencils are DPP wave shifts (no LDS).
-//   * x, g, xp, gp, d live in VGPRs (3 scalars per lane each); the L-BFGS history
-//     (m x {s,y}) lives in LDS, one column per interior control point: HBM sees the initial
-//     control points and the result only.
-//   * every scalar of the More-Thuente search is replicated across the group's lanes; the
-//     two groups of a wave diverge freely (exec masking), all cross-lane traffic stays
-//     inside a group.
-//   * per-trajectory sums (cost terms, dot products) are butterfly all-reduces inside the
-//     group: v += lane[i ^ m], m = 1,2,..,GROUP/2 — a fixed tree, so results are
-//     deterministic and reproducible bit-for-bit by oracle/vigo_oracle.c's emulation mode.
+//   * one 64-lane wavefront per workgroup; a trajectory owns a lane GROUP of 32 (N <= 32, two
+//     trajectories per wave) or 64 lanes; a lane owns PPL consecutive control points (1 for
+//     N <= 64, 2 for N <= 128, 4 beyond), so the 4-point jerk stencil and the 2/3-point vel/acc
+//     stencils are register renames plus DPP wave shifts (no LDS).
+//   * x, g, xp, gp, d live in VGPRs (3 scalars per owned point each); the L-BFGS history
+//     (m x {s,y}) lives in LDS, one 48-byte record per free control point and slot: HBM sees the
+//     initial control points and the result only.
+//   * every scalar of the More-Thuente search is replicated across the group's lanes; the two
+//     groups of a wave diverge freely (exec masking), all cross-lane traffic stays inside a group.
+//   * per-trajectory sums (cost terms, dot products) are: a per-point partial, the lane's
+//     points added in index order, then a butterfly all-reduce inside the group,
+//     v += lane[i ^ m], m = 1,2,..,GROUP/2 — a fixed tree, so results are deterministic and
+//     reproducible bit-for-bit by oracle/vigo_oracle.c's emulation mode.
 //
 // Arithmetic follows the reference expression by expression (bsplineTraj.cpp:802-1064 and
 // solver/lbfgs.hpp:295-1349; see the citations on each block); the file is built with
@@ -83,6 +84,24 @@ __device__ __forceinline__ float from_next(float v) {
     return __int_as_float(dpp_next_i32(__float_as_int(v)));
 }
 
+// Shift of a per-lane run of PPL consecutive control-point values by one point along the
+// trajectory: o[q] = value of point (own + q + 1) resp. (own + q - 1).  Inside the lane that is
+// a register rename, across lanes one DPP shift.
+template <typename T, int PPL>
+__device__ __forceinline__ void seq_next(const T (&a)[PPL], T (&o)[PPL]) {
+    const T edge = from_next(a[0]);
+#pragma unroll
+    for (int q = 0; q + 1 < PPL; ++q) o[q] = a[q + 1];
+    o[PPL - 1] = edge;
+}
+template <typename T, int PPL>
+__device__ __forceinline__ void seq_prev(const T (&a)[PPL], T (&o)[PPL]) {
+    const T edge = from_prev(a[PPL - 1]);
+#pragma unroll
+    for (int q = PPL - 1; q > 0; --q) o[q] = a[q - 1];
+    o[0] = edge;
+}
+
 // Butterfly all-reduce of K independent values inside a GROUP-lane group, as VALU-speed DPP
 // moves instead of ds_bpermute round trips.  The tree is the xor butterfly
 // v += lane[i ^ m], m = 1, 2, 4, ..., GROUP/2:
@@ -139,6 +158,19 @@ __device__ __forceinline__ double group_sum1(double v) {
 
 __device__ __forceinline__ double sum3(double a, double b, double c) { return (a + b) + c; }
 
+template <typename T>
+__device__ __forceinline__ double dot3(const T (&a)[3], const T (&b)[3]) {
+    return sum3((double)a[0] * (double)b[0], (double)a[1] * (double)b[1], (double)a[2] * (double)b[2]);
+}
+// lane partial of a dot product: the lane's points in index order, starting from 0
+template <typename T, int PPL>
+__device__ __forceinline__ double dot_lane(const T (&a)[PPL][3], const T (&b)[PPL][3]) {
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) s += dot3(a[q], b[q]);
+    return s;
+}
+
 // one L-BFGS history pair of one control point as it sits in LDS (48 B in fp64: three
 // conflict-free ds_read_b128 per lane, one address register)
 template <typename T>
@@ -148,19 +180,21 @@ struct alignas(16) HPair {
 };
 
 // per-lane view of one trajectory's inputs
-constexpr int kGuideRegs = 2;  // guide pairs per control point kept in VGPRs (more: re-read from HBM/L2)
-template <typename T>
+template <typename T, int PPL>
 struct LaneProblem {
+    // guide pairs per control point kept in VGPRs (more: re-read from HBM/L2 every evaluation)
+    static constexpr int kGuideRegs = (PPL == 1) ? 2 : 0;
+    static constexpr int kGuideDim = kGuideRegs > 0 ? kGuideRegs : 1;
     int N;
-    int p;            // control point of this lane
-    bool has_pt;      // p < N
-    bool interior;    // 3 <= p <= N-4 (a free control point)
-    int g_begin, g_end;  // this control point's guide pairs
+    int p0;                   // first control point of this lane
+    bool has_pt[PPL];         // p0 + q < N
+    bool interior[PPL];       // 3 <= p0 + q <= N-4 (a free control point)
+    int g_begin[PPL], g_end[PPL];
     const double* gpv;
     const uint8_t* gunk;
-    T gq[kGuideRegs][6];     // the first pairs, loaded once per solve (they never move)
-    bool gqu[kGuideRegs];
-    int o_begin, o_end;  // this trajectory's obstacles
+    T gq[kGuideDim][6];       // (PPL == 1) the first pairs, loaded once per solve: they never move
+    bool gqu[kGuideDim];
+    int o_begin, o_end;       // this trajectory's obstacles
     const double* obs;
     double w[4];
 };
@@ -197,210 +231,230 @@ __device__ __forceinline__ void guide_pair_term(const DevConst& K, const T (&c)[
     Gd[0] += gx; Gd[1] += gy; Gd[2] += gz;
 }
 
-template <typename T>
-__device__ __forceinline__ double dot3(const T (&a)[3], const T (&b)[3]) {
-    return sum3((double)a[0] * (double)b[0], (double)a[1] * (double)b[1], (double)a[2] * (double)b[2]);
-}
-
-// ---- cost + gradient at the point held in c (BT.cpp:802-821) ---------------------------
+// ---- cost + gradient at the points held in c (BT.cpp:802-821) ---------------------------
 // T is the element type of points/gradients; sums are fp64.  g receives the weighted gradient
-// on interior lanes, 0 elsewhere.  ONE 7-value group reduction returns
+// of the free points, 0 elsewhere.  ONE 7-value group reduction returns
 //   sums[0..3] = un-weighted distance / smoothness / feasibility / dynamic costs,
 //   sums[4] = g.d, sums[5] = x.x over the free points, sums[6] = g.g
 // (the line search needs g.d after every evaluation, LB:829, and the norms after the last one,
 // LB:1200-1201; fusing them costs three more DPP chains instead of two more reductions).
 // Returns the weighted total cost (group-uniform).
-template <typename T, int GROUP>
-__device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LaneProblem<T>& Q, const T (&c)[3],
-                                                 const T (&d)[3], T (&g)[3], double (&sums)[7]) {
-    const int N = Q.N, p = Q.p;
-    // forward window c[p+1..p+3] by chained DPP shifts
-    T p1[3], p2[3], p3[3];
+template <typename T, int GROUP, int PPL>
+__device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LaneProblem<T, PPL>& Q,
+                                                 const T (&c)[PPL][3], const T (&d)[PPL][3], T (&g)[PPL][3],
+                                                 double (&sums)[7]) {
+    using LP = LaneProblem<T, PPL>;
+    const int N = Q.N;
+    T Gd[PPL][3], Gs[PPL][3], Gf[PPL][3], Go[PPL][3];
+    double pt_s[PPL], pt_f[PPL], pt_d[PPL], pt_o[PPL];  // per-point cost partials
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        p1[a] = from_next(c[a]);
-        p2[a] = from_next(p1[a]);
-        p3[a] = from_next(p2[a]);
+    for (int q = 0; q < PPL; ++q) {
+        pt_s[q] = pt_f[q] = pt_d[q] = pt_o[q] = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) Gd[q][a] = Go[q][a] = T(0);
     }
 
-    T Gd[3] = {0, 0, 0}, Gs[3] = {0, 0, 0}, Gf[3] = {0, 0, 0}, Go[3] = {0, 0, 0};
-    double part[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-
-    // Every lane evaluates the stencil term whose FIRST point it owns (index i = p): jerk_p,
-    // velocity_p, acceleration_p and their gradient magnitudes.  A control point's gradient is
-    // the reference's scatter-add seen from the receiving column: the terms of i = p-3..p, which
-    // are the SAME expressions evaluated by the lanes below, fetched with DPP shifts — identical
-    // bits, no recomputation (and half the fp64 divisions by ts).
-
-    // ---- smoothness, BT.cpp:934-950 ----
-    {
-        T gt0[3];  // gradTemp = 2 * jerk_i, i = p
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const T J0 = ((p3[a] - 3 * p2[a]) + 3 * p1[a]) - c[a];
-            gt0[a] = T(2.0) * J0;
-            Gs[a] = J0;  // parked for the cost below
-        }
-        if (Q.has_pt && p <= N - 4)
-            part[1] = sum3((double)(Gs[0] * Gs[0]), (double)(Gs[1] * Gs[1]), (double)(Gs[2] * Gs[2]));
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const T gt1 = from_prev(gt0[a]);   // i = p-1
-            const T gt2 = from_prev(gt1);      // i = p-2
-            const T gt3 = from_prev(gt2);      // i = p-3
-            T acc = gt3;                       // i=p-3: col(i+3) += gradTemp
-            acc += T(-3.0) * gt2;              // i=p-2: col(i+2) += -3*gradTemp
-            acc += T(3.0) * gt1;               // i=p-1: col(i+1) += 3*gradTemp
-            acc += -gt0[a];                    // i=p  : col(i)   += -gradTemp
-            Gs[a] = acc;
-        }
-    }
-
-    // ---- feasibility, BT.cpp:952-999 (limits hard-coded to 1.0, :955-956) ----
+    // Every point evaluates the stencil term whose FIRST point it is (index i = its own): jerk_i,
+    // velocity_i, acceleration_i and their gradient magnitudes.  A control point's gradient is the
+    // reference's scatter-add seen from the receiving column: the terms of i-3..i, which are the
+    // SAME expressions evaluated at the points below, fetched with register renames / DPP shifts —
+    // identical bits, no recomputation (and half the fp64 divisions by ts).
     {
         const T ts = (T)K.ts_ctrl, tis = (T)K.ts_inv_sqr;
         auto excess = [](T v) -> T { return v > T(1.0) ? v - T(1.0) : (v < T(-1.0) ? v + T(1.0) : T(0.0)); };
-        double cfv = 0.0, ea2[3];
+        double jj[PPL][3], vv[PPL][3], aa[PPL][3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const T evP = excess((p1[a] - c[a]) / ts);                   // velocity i = p
-            const T eaP = excess(((p2[a] - 2 * p1[a]) + c[a]) * tis);    // acceleration i = p
-            // gradient(j,i+1) += 2(v-vmax)/ts*tsInvSqr, gradient(j,i) += the negation (exactly)
-            const T gv = (T(2) * evP) / ts * tis;
-            // gradient(j,i) and (j,i+2) += 2(a-amax)*tsInvSqr, gradient(j,i+1) += -4(...) = -2x that (exactly)
-            const T ga = (T(2) * eaP) * tis;
-            const T gvM = from_prev(gv);       // velocity i = p-1
-            const T gaM1 = from_prev(ga);      // acceleration i = p-1
-            const T gaM2 = from_prev(gaM1);    // acceleration i = p-2
-            T acc = gvM;                       // i=p-1: gradient(j,i+1)
-            acc += -gv;                        // i=p  : gradient(j,i)
-            acc += gaM2;                       // i=p-2: gradient(j,i+2)
-            acc += -(T(2) * gaM1);             // i=p-1: gradient(j,i+1)
-            acc += ga;                         // i=p  : gradient(j,i)
-            Gf[a] = acc;
-            cfv += (double)((evP * evP) * tis);
-            ea2[a] = (double)(eaP * eaP);
+            T C[PPL], P1[PPL], P2[PPL], P3[PPL];
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) C[q] = c[q][a];
+            seq_next<T, PPL>(C, P1);
+            seq_next<T, PPL>(P1, P2);
+            seq_next<T, PPL>(P2, P3);
+            T gt0[PPL], gv[PPL], ga[PPL];
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                // smoothness, BT.cpp:934-950
+                const T J0 = ((P3[q] - 3 * P2[q]) + 3 * P1[q]) - C[q];
+                gt0[q] = T(2.0) * J0;                                          // gradTemp
+                jj[q][a] = (double)(J0 * J0);
+                // feasibility, BT.cpp:952-999 (limits hard-coded to 1.0, :955-956)
+                const T evP = excess((P1[q] - C[q]) / ts);                     // velocity i
+                const T eaP = excess(((P2[q] - 2 * P1[q]) + C[q]) * tis);      // acceleration i
+                // gradient(j,i+1) += 2(v-vmax)/ts*tsInvSqr, gradient(j,i) += the negation (exactly)
+                gv[q] = (T(2) * evP) / ts * tis;
+                // gradient(j,i), (j,i+2) += 2(a-amax)*tsInvSqr; gradient(j,i+1) += -4(..) = -2x that (exactly)
+                ga[q] = (T(2) * eaP) * tis;
+                vv[q][a] = (double)((evP * evP) * tis);
+                aa[q][a] = (double)(eaP * eaP);
+            }
+            T gt1[PPL], gt2[PPL], gt3[PPL], gvM[PPL], gaM1[PPL], gaM2[PPL];
+            seq_prev<T, PPL>(gt0, gt1);
+            seq_prev<T, PPL>(gt1, gt2);
+            seq_prev<T, PPL>(gt2, gt3);
+            seq_prev<T, PPL>(gv, gvM);
+            seq_prev<T, PPL>(ga, gaM1);
+            seq_prev<T, PPL>(gaM1, gaM2);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                T acc = gt3[q];                    // i-3: col(i+3) += gradTemp
+                acc += T(-3.0) * gt2[q];           // i-2: col(i+2) += -3*gradTemp
+                acc += T(3.0) * gt1[q];            // i-1: col(i+1) += 3*gradTemp
+                acc += -gt0[q];                    // i  : col(i)   += -gradTemp
+                Gs[q][a] = acc;
+                T fcc = gvM[q];                    // i-1: gradient(j,i+1)
+                fcc += -gv[q];                     // i  : gradient(j,i)
+                fcc += gaM2[q];                    // i-2: gradient(j,i+2)
+                fcc += -(T(2) * gaM1[q]);          // i-1: gradient(j,i+1)
+                fcc += ga[q];                      // i  : gradient(j,i)
+                Gf[q][a] = fcc;
+            }
         }
-        // cost partial of lane p: velocity i=p (x,y,z) then acceleration i=p (x,y,z)
-        double cf = 0.0;
-        if (Q.has_pt && p <= N - 2) cf = cfv;
-        if (Q.has_pt && p <= N - 3) { cf += ea2[0]; cf += ea2[1]; cf += ea2[2]; }
-        part[2] = cf;
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            const int p = Q.p0 + q;
+            if (Q.has_pt[q] && p <= N - 4) pt_s[q] = sum3(jj[q][0], jj[q][1], jj[q][2]);
+            // velocity i (x,y,z) then acceleration i (x,y,z)
+            double cf = 0.0;
+            if (Q.has_pt[q] && p <= N - 2) cf = (vv[q][0] + vv[q][1]) + vv[q][2];
+            if (Q.has_pt[q] && p <= N - 3) { cf += aa[q][0]; cf += aa[q][1]; cf += aa[q][2]; }
+            pt_f[q] = cf;
+        }
     }
 
     // ---- guide-point distance, BT.cpp:823-932 ----
-    if (Q.interior) {
-        double cd = 0.0;
-        const int cnt = Q.g_end - Q.g_begin;
 #pragma unroll
-        for (int j = 0; j < kGuideRegs; ++j) {
-            if (j < cnt)
-                guide_pair_term<T>(K, c, Q.gq[j][0], Q.gq[j][1], Q.gq[j][2], Q.gq[j][3], Q.gq[j][4], Q.gq[j][5],
-                                   Q.gqu[j], cd, Gd);
-        }
-        for (int j = Q.g_begin + kGuideRegs; j < Q.g_end; ++j) {
-            const double* pv = Q.gpv + 6 * (size_t)j;
-            guide_pair_term<T>(K, c, (T)pv[0], (T)pv[1], (T)pv[2], (T)pv[3], (T)pv[4], (T)pv[5],
-                               Q.gunk ? (Q.gunk[j] != 0) : false, cd, Gd);
-        }
-        if (K.plan_in_z) {
-            // BT.cpp:897-930, reproduced with its x-row gradient and heightDistMax band test
-            const T hth = (T)K.hth, ha = (T)K.ha, hb = (T)K.hb, hc = (T)K.hc;
-            const T hmin = c[2] - (T)K.min_h, hmax = c[2] - (T)K.max_h;
-            if (hmin < T(0)) {
-                const T e = hth - hmin;
-                cd += (double)((ha * (e * e) + hb * e) + hc);
-                Gd[0] += -((T(2) * ha) * e + hb) * T(-1.0);
-            } else if (hmin >= T(0) && hmax < hth) {
-                const T e = hth - hmin;
-                cd += (double)((e * e) * e);
-                Gd[0] += T(-3.0) * (e * e) * T(-1.0);
+    for (int q = 0; q < PPL; ++q) {
+        if (Q.interior[q]) {
+            double cd = 0.0;
+            const int cnt = Q.g_end[q] - Q.g_begin[q];
+#pragma unroll
+            for (int j = 0; j < LP::kGuideRegs; ++j) {
+                if (j < cnt)
+                    guide_pair_term<T>(K, c[q], Q.gq[j][0], Q.gq[j][1], Q.gq[j][2], Q.gq[j][3], Q.gq[j][4], Q.gq[j][5],
+                                       Q.gqu[j], cd, Gd[q]);
             }
-            if (hmax > T(0)) {
-                const T e = hth + hmax;
-                cd += (double)((ha * (e * e) + hb * e) + hc);
-                Gd[0] += -((T(2) * ha) * e + hb) * T(1.0);
-            } else if (hmax <= T(0) && hmax >= -hth) {
-                const T e = hth + hmax;
-                cd += (double)((e * e) * e);
-                Gd[0] += T(-3.0) * (e * e) * T(1.0);
+            for (int j = Q.g_begin[q] + LP::kGuideRegs; j < Q.g_end[q]; ++j) {
+                const double* pv = Q.gpv + 6 * (size_t)j;
+                guide_pair_term<T>(K, c[q], (T)pv[0], (T)pv[1], (T)pv[2], (T)pv[3], (T)pv[4], (T)pv[5],
+                                   Q.gunk ? (Q.gunk[j] != 0) : false, cd, Gd[q]);
             }
+            if (K.plan_in_z) {
+                // BT.cpp:897-930, reproduced with its x-row gradient and heightDistMax band test
+                const T hth = (T)K.hth, ha = (T)K.ha, hb = (T)K.hb, hc = (T)K.hc;
+                const T hmin = c[q][2] - (T)K.min_h, hmax = c[q][2] - (T)K.max_h;
+                if (hmin < T(0)) {
+                    const T e = hth - hmin;
+                    cd += (double)((ha * (e * e) + hb * e) + hc);
+                    Gd[q][0] += -((T(2) * ha) * e + hb) * T(-1.0);
+                } else if (hmin >= T(0) && hmax < hth) {
+                    const T e = hth - hmin;
+                    cd += (double)((e * e) * e);
+                    Gd[q][0] += T(-3.0) * (e * e) * T(-1.0);
+                }
+                if (hmax > T(0)) {
+                    const T e = hth + hmax;
+                    cd += (double)((ha * (e * e) + hb * e) + hc);
+                    Gd[q][0] += -((T(2) * ha) * e + hb) * T(1.0);
+                } else if (hmax <= T(0) && hmax >= -hth) {
+                    const T e = hth + hmax;
+                    cd += (double)((e * e) * e);
+                    Gd[q][0] += T(-3.0) * (e * e) * T(1.0);
+                }
+            }
+            pt_d[q] = cd;
         }
-        part[0] = cd;
     }
 
     // ---- dynamic obstacles, BT.cpp:1001-1064 ----
-    if (Q.interior && Q.o_end > Q.o_begin) {
+    if (Q.o_end > Q.o_begin) {
         const T thr0 = (T)K.thr_dyn, oa = (T)K.oa, ob = (T)K.ob, oc = (T)K.oc;
-        double co = 0.0;
-        for (int j = Q.o_begin; j < Q.o_end; ++j) {
-            const double* o = Q.obs + 9 * (size_t)j;
-            const T opx = (T)o[0], opy = (T)o[1], ovx = (T)o[3], ovy = (T)o[4];
-            const T hx = (T)o[6] / 2, hy = (T)o[7] / 2;
-            const T size = sqrt(hx * hx + hy * hy);
-            for (int n = 0; n <= K.pred_num; n += 2) {  // skipFactor = 2, BT.cpp:1006
-                const T tn = (T)((double)n * K.ts);
-                const T px = opx + tn * ovx, py = opy + tn * ovy;
-                // integer division n/predictionNum, BT.cpp:1020
-                const T thr = (T(1) - (T)(n / K.pred_num) * T(0.2)) * thr0;
-                const T dx = c[0] - px, dy = c[1] - py, dz = T(0.0);
-                const T nrm = sqrt((dx * dx + dy * dy) + dz * dz);
-                const T e = thr - (nrm - size);
-                const T gx = dx / nrm, gy = dy / nrm, gz = dz / nrm;
-                if (e <= T(0)) {
-                    // no punishment
-                } else if (e > T(0) && e <= thr) {
-                    co += (double)((e * e) * e);
-                    const T k = T(-3.0) * (e * e);
-                    Go[0] += k * gx; Go[1] += k * gy; Go[2] += k * gz;
-                } else if (e >= thr) {
-                    co += (double)((oa * (e * e) + ob * e) + oc);
-                    const T k = -((T(2) * oa) * e + ob);
-                    Go[0] += k * gx; Go[1] += k * gy; Go[2] += k * gz;
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            if (!Q.interior[q]) continue;
+            double co = 0.0;
+            for (int j = Q.o_begin; j < Q.o_end; ++j) {
+                const double* o = Q.obs + 9 * (size_t)j;
+                const T opx = (T)o[0], opy = (T)o[1], ovx = (T)o[3], ovy = (T)o[4];
+                const T hx = (T)o[6] / 2, hy = (T)o[7] / 2;
+                const T size = sqrt(hx * hx + hy * hy);
+                for (int n = 0; n <= K.pred_num; n += 2) {  // skipFactor = 2, BT.cpp:1006
+                    const T tn = (T)((double)n * K.ts);
+                    const T px = opx + tn * ovx, py = opy + tn * ovy;
+                    // integer division n/predictionNum, BT.cpp:1020
+                    const T thr = (T(1) - (T)(n / K.pred_num) * T(0.2)) * thr0;
+                    const T dx = c[q][0] - px, dy = c[q][1] - py, dz = T(0.0);
+                    const T nrm = sqrt((dx * dx + dy * dy) + dz * dz);
+                    const T e = thr - (nrm - size);
+                    const T gx = dx / nrm, gy = dy / nrm, gz = dz / nrm;
+                    if (e <= T(0)) {
+                        // no punishment
+                    } else if (e > T(0) && e <= thr) {
+                        co += (double)((e * e) * e);
+                        const T k = T(-3.0) * (e * e);
+                        Go[q][0] += k * gx; Go[q][1] += k * gy; Go[q][2] += k * gz;
+                    } else if (e >= thr) {
+                        co += (double)((oa * (e * e) + ob * e) + oc);
+                        const T k = -((T(2) * oa) * e + ob);
+                        Go[q][0] += k * gx; Go[q][1] += k * gy; Go[q][2] += k * gz;
+                    }
                 }
             }
+            pt_o[q] = co;
         }
-        part[3] = co;
     }
 
     const T w0 = (T)Q.w[0], w1 = (T)Q.w[1], w2 = (T)Q.w[2], w3 = (T)Q.w[3];
+    double part[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
-        g[a] = Q.interior ? (((w0 * Gd[a] + w1 * Gs[a]) + w2 * Gf[a]) + w3 * Go[a]) : T(0);
-    part[4] = dot3(g, d);
-    part[5] = Q.interior ? dot3(c, c) : 0.0;
-    part[6] = dot3(g, g);
+    for (int q = 0; q < PPL; ++q) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            g[q][a] = Q.interior[q] ? (((w0 * Gd[q][a] + w1 * Gs[q][a]) + w2 * Gf[q][a]) + w3 * Go[q][a]) : T(0);
+        part[0] += pt_d[q];
+        part[1] += pt_s[q];
+        part[2] += pt_f[q];
+        part[3] += pt_o[q];
+        part[4] += dot3(g[q], d[q]);
+        part[5] += Q.interior[q] ? dot3(c[q], c[q]) : 0.0;
+        part[6] += dot3(g[q], g[q]);
+    }
     group_sum<GROUP, 7>(part);
 #pragma unroll
     for (int q = 0; q < 7; ++q) sums[q] = part[q];
     return ((Q.w[0] * part[0] + Q.w[1] * part[1]) + Q.w[2] * part[2]) + Q.w[3] * part[3];
 }
 
-template <typename T, int GROUP>
-__device__ __forceinline__ void load_problem(const SolveArgs& A, const DevConst& K, int b, int p,
-                                             LaneProblem<T>& Q) {
+template <typename T, int GROUP, int PPL>
+__device__ __forceinline__ void load_problem(const SolveArgs& A, const DevConst& K, int b, int lane_in_group,
+                                             LaneProblem<T, PPL>& Q) {
+    using LP = LaneProblem<T, PPL>;
     const int N = A.N;
     Q.N = N;
-    Q.p = p;
-    Q.has_pt = p < N;
-    Q.interior = (p >= 3) && (p <= N - 4);
+    Q.p0 = lane_in_group * PPL;
     Q.gpv = A.guide_pv;
     Q.gunk = A.guide_unk;
-    Q.g_begin = Q.g_end = 0;
-    if (Q.interior && A.guide_off) {
-        Q.g_begin = A.guide_off[(size_t)b * N + p];
-        Q.g_end = A.guide_off[(size_t)b * N + p + 1];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        const int p = Q.p0 + q;
+        Q.has_pt[q] = p < N;
+        Q.interior[q] = (p >= 3) && (p <= N - 4);
+        Q.g_begin[q] = Q.g_end[q] = 0;
+        if (Q.interior[q] && A.guide_off) {
+            Q.g_begin[q] = A.guide_off[(size_t)b * N + p];
+            Q.g_end[q] = A.guide_off[(size_t)b * N + p + 1];
+        }
     }
 #pragma unroll
-    for (int j = 0; j < kGuideRegs; ++j) {
+    for (int j = 0; j < LP::kGuideDim; ++j) {
         Q.gqu[j] = false;
 #pragma unroll
         for (int q = 0; q < 6; ++q) Q.gq[j][q] = T(0);
-        if (Q.g_begin + j < Q.g_end) {
-            const double* pv = A.guide_pv + 6 * (size_t)(Q.g_begin + j);
+        if (j < LP::kGuideRegs && Q.g_begin[0] + j < Q.g_end[0]) {
+            const double* pv = A.guide_pv + 6 * (size_t)(Q.g_begin[0] + j);
 #pragma unroll
             for (int q = 0; q < 6; ++q) Q.gq[j][q] = (T)pv[q];
-            Q.gqu[j] = A.guide_unk ? (A.guide_unk[Q.g_begin + j] != 0) : false;
+            Q.gqu[j] = A.guide_unk ? (A.guide_unk[Q.g_begin[0] + j] != 0) : false;
         }
     }
     Q.obs = A.obs;
@@ -420,30 +474,52 @@ __device__ __forceinline__ void load_problem(const SolveArgs& A, const DevConst&
     }
 }
 
+template <typename T, int PPL>
+__device__ __forceinline__ void load_points(const SolveArgs& A, int b, const LaneProblem<T, PPL>& Q, T (&x)[PPL][3]) {
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        x[q][0] = x[q][1] = x[q][2] = T(0);
+        if (Q.has_pt[q]) {
+            const double* src = A.ctrl + ((size_t)b * A.N + Q.p0 + q) * 3;
+            x[q][0] = (T)src[0]; x[q][1] = (T)src[1]; x[q][2] = (T)src[2];
+        }
+    }
+}
+
+template <typename T, int PPL>
+__device__ __forceinline__ void store_points(const SolveArgs& A, int b, const LaneProblem<T, PPL>& Q, const T (&x)[PPL][3]) {
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        if (Q.has_pt[q]) {
+            double* dst = A.ctrl + ((size_t)b * A.N + Q.p0 + q) * 3;
+            dst[0] = (double)x[q][0]; dst[1] = (double)x[q][1]; dst[2] = (double)x[q][2];
+        }
+    }
+}
+
 // ---- standalone cost/gradient kernel (vigo_cost_grad) ----------------------------------
-template <typename T, int GROUP>
+template <typename T, int GROUP, int PPL>
 __global__ void __launch_bounds__(kWave) k_cost_grad(SolveArgs A, DevConst K) {
     constexpr int TPB = kWave / GROUP;
     const int lane = threadIdx.x;
-    const int p = lane % GROUP;
     const int b = blockIdx.x * TPB + lane / GROUP;
     if (b >= A.B) return;
-    LaneProblem<T> Q;
-    load_problem<T, GROUP>(A, K, b, p, Q);
-    T c[3] = {0, 0, 0};
-    if (Q.has_pt) {
-        const double* src = A.ctrl + ((size_t)b * A.N + p) * 3;
-        c[0] = (T)src[0]; c[1] = (T)src[1]; c[2] = (T)src[2];
-    }
-    T g[3];
-    const T zero[3] = {0, 0, 0};
+    LaneProblem<T, PPL> Q;
+    load_problem<T, GROUP, PPL>(A, K, b, lane % GROUP, Q);
+    T c[PPL][3], g[PPL][3], zero[PPL][3];
+    load_points<T, PPL>(A, b, Q, c);
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) zero[q][0] = zero[q][1] = zero[q][2] = T(0);
     double sums[7];
-    const double f = eval_cost_grad<T, GROUP>(K, Q, c, zero, g, sums);
-    if (Q.interior && A.out_grad) {
-        double* dst = A.out_grad + ((size_t)b * (A.N - 6) + (p - 3)) * 3;
-        dst[0] = (double)g[0]; dst[1] = (double)g[1]; dst[2] = (double)g[2];
+    const double f = eval_cost_grad<T, GROUP, PPL>(K, Q, c, zero, g, sums);
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        if (Q.interior[q] && A.out_grad) {
+            double* dst = A.out_grad + ((size_t)b * (A.N - 6) + (Q.p0 + q - 3)) * 3;
+            dst[0] = (double)g[q][0]; dst[1] = (double)g[q][1]; dst[2] = (double)g[q][2];
+        }
     }
-    if (p == 0) {
+    if (lane % GROUP == 0) {
         if (A.out_cost) A.out_cost[b] = f;
         if (A.out_terms) {
 #pragma unroll
@@ -563,13 +639,16 @@ __device__ __forceinline__ int trial_interval(double& xt, double& xf, double& xd
 }
 
 // ---- whole-solve kernel (vigo_optimize): BT.cpp:687-718 + LB:1024-1349 -------------------
-// LDS: hist[(slot*2 + {0:s,1:y})*3 + axis][ROW] of T with ROW = TPB*(N-6) columns (each lane
-//      reads and writes only its own column: LDS is a per-lane register extension here, no
-//      cross-lane traffic and no barriers), then ys[slot][TPB] and alpha[age][TPB] doubles.
+// LDS: hist[slot][ROW] of HPair<T> with ROW = TPB*(N-6) columns (each lane reads and writes only
+//      the columns of its own points: LDS is a per-lane register extension here, no cross-lane
+//      traffic and no barriers), then ys[slot][TPB] and alpha[age][TPB] doubles.
 // Control flow: an outer trip per L-BFGS iteration (trip 0 = the initial evaluation) with ONE
 // evaluation site inside the line-search loop, so the two groups of a wave re-converge at every
 // iteration boundary and run the (dominant) two-loop recursion together.
-template <typename T, int GROUP>
+#ifndef VIGO_TWOLOOP_WIN
+#define VIGO_TWOLOOP_WIN 2
+#endif
+template <typename T, int GROUP, int PPL>
 __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) {
     constexpr int TPB = kWave / GROUP;
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -581,27 +660,31 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
 
     const int lane = threadIdx.x;
     const int grp = lane / GROUP;
-    const int p = lane % GROUP;
     const int b = blockIdx.x * TPB + grp;
     if (b >= A.B) return;
 
-    LaneProblem<T> Q;
-    load_problem<T, GROUP>(A, K, b, p, Q);
-    // this lane's history column.  Lanes that own no free point (p < 3, p > N-4) read a
+    LaneProblem<T, PPL> Q;
+    load_problem<T, GROUP, PPL>(A, K, b, lane % GROUP, Q);
+    // history column of each owned point.  Points that are not free (index < 3 or > N-4) read a
     // neighbour's column — finite data their zero d/g wipes out — and never write.
-    const int pc = (p < 3) ? 3 : ((p > N - 4) ? N - 4 : p);
-    HPair<T>* hl = hist + (grp * NI + (pc - 3));
+    HPair<T>* hl[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        const int p = Q.p0 + q;
+        const int pc = (p < 3) ? 3 : ((p > N - 4) ? N - 4 : p);
+        hl[q] = hist + (grp * NI + (pc - 3));
+    }
     double* ys_l = ys_tab + grp;
     double* al_l = ys_tab + (size_t)m * TPB + grp;
 
-    // x holds this lane's control point: a free variable on interior lanes, a fixed boundary
-    // point elsewhere (its g, d, s, y are identically zero so it never moves).
-    T x[3] = {0, 0, 0};
-    if (Q.has_pt) {
-        const double* src = A.ctrl + ((size_t)b * N + p) * 3;
-        x[0] = (T)src[0]; x[1] = (T)src[1]; x[2] = (T)src[2];
-    }
-    T g[3] = {0, 0, 0}, xp[3] = {0, 0, 0}, gp[3] = {0, 0, 0}, d[3] = {0, 0, 0};
+    // x holds this lane's control points: free variables where interior, fixed boundary points
+    // elsewhere (their g, d, s, y are identically zero so they never move).
+    T x[PPL][3], g[PPL][3], xp[PPL][3], gp[PPL][3], d[PPL][3];
+    load_points<T, PPL>(A, b, Q, x);
+#pragma unroll
+    for (int q = 0; q < PPL; ++q)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) g[q][a] = xp[q][a] = gp[q][a] = d[q][a] = T(0);
     double sums[7];
     int evals = 0;
     int ret = LBERR_UNKNOWN;
@@ -619,8 +702,10 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
         bool run = true;
         if (!first) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { xp[a] = x[a]; gp[a] = g[a]; }  // LB:1172-1173
-            dginit = sums[4];  // g.d for the d just built: reduced below with the two-loop's last step
+            for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { xp[q][a] = x[q][a]; gp[q][a] = g[q][a]; }  // LB:1172-1173
+            dginit = sums[4];  // g.d for the d just built (reduced at the end of the two-loop below)
             if (step <= 0.) { ls = LBERR_INVALIDPARAMETERS; run = false; }
             else if (0 < dginit) { ls = LBERR_INCREASEGRADIENT; run = false; }
             finit = fx;
@@ -649,10 +734,12 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
                 }
                 // x <- xp + step * d  (LB:824-825)
 #pragma unroll
-                for (int a = 0; a < 3; ++a) x[a] = xp[a] + (T)step * d[a];
+                for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) x[q][a] = xp[q][a] + (T)step * d[q][a];
             }
 
-            fx = eval_cost_grad<T, GROUP>(K, Q, x, d, g, sums);  // the only evaluation site (LB:828, :1132)
+            fx = eval_cost_grad<T, GROUP, PPL>(K, Q, x, d, g, sums);  // the only evaluation site (LB:828, :1132)
             ++evals;
             if (first) break;
 
@@ -693,7 +780,9 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
         if (first) {
             first = false;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) d[a] = -g[a];  // LB:1144
+            for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) d[q][a] = -g[q][a];  // LB:1144
             if (xnorm < 1.0) xnorm = 1.0;
             if (gnorm / xnorm <= K.g_epsilon) { ret = LB_ALREADY_MINIMIZED; break; }  // LB:1154-1157
             // d = -g: d.d = g.g and g.d = -(g.g) exactly (negation commutes with every rounding)
@@ -707,12 +796,11 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
         if (ls < 0) {
             // LB:1189-1197.  optData_.controlPoints keeps the last trial (BT.cpp:803): write it
             // out now, then revert x like the reference does.
-            if (Q.has_pt) {
-                double* dst = A.ctrl + ((size_t)b * N + p) * 3;
-                dst[0] = (double)x[0]; dst[1] = (double)x[1]; dst[2] = (double)x[2];
-            }
+            store_points<T, PPL>(A, b, Q, x);
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { x[a] = xp[a]; g[a] = gp[a]; }
+            for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { x[q][a] = xp[q][a]; g[q][a] = gp[q][a]; }
             ret = ls;
             break;
         }
@@ -723,16 +811,19 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
         if (K.max_iterations != 0 && K.max_iterations < k + 1) { ret = LBERR_MAXIMUMITERATION; break; }
 
         // s, y, ys, yy — LB:1264-1276
-        T sv[3], yv[3];
+        T sv[PPL][3], yv[PPL][3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { sv[a] = x[a] - xp[a]; yv[a] = g[a] - gp[a]; }
-        if (Q.interior) {
-            HPair<T> hp;
+        for (int q = 0; q < PPL; ++q) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { hp.s[a] = sv[a]; hp.y[a] = yv[a]; }
-            hl[end * ROW] = hp;
+            for (int a = 0; a < 3; ++a) { sv[q][a] = x[q][a] - xp[q][a]; yv[q][a] = g[q][a] - gp[q][a]; }
+            if (Q.interior[q]) {
+                HPair<T> hp;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { hp.s[a] = sv[q][a]; hp.y[a] = yv[q][a]; }
+                hl[q][end * ROW] = hp;
+            }
         }
-        double ysyy[2] = {dot3(yv, sv), dot3(yv, yv)};
+        double ysyy[2] = {dot_lane<T, PPL>(yv, sv), dot_lane<T, PPL>(yv, yv)};
         group_sum<GROUP, 2>(ysyy);
         const double ys = ysyy[0], yy = ysyy[1];
         ys_l[end * TPB] = ys;
@@ -746,24 +837,28 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
         const int newest = end;                        // slot of the pair just stored (age 0)
         end = (end + 1 == m) ? 0 : end + 1;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) d[a] = -g[a];
+        for (int q = 0; q < PPL; ++q)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) d[q][a] = -g[q][a];
 
-#ifndef VIGO_TWOLOOP_WIN
-#define VIGO_TWOLOOP_WIN 2
-#endif
         constexpr int kWin = VIGO_TWOLOOP_WIN;
-        T Ps[kWin][3], Py[kWin][3];
+        T Ps[kWin][PPL][3], Py[kWin][PPL][3];
         double Pys[kWin];
-        auto fetch = [&](int age, T (&s_)[3], T (&y_)[3], double& ys_) {
+        auto fetch = [&](int age, T (&s_)[PPL][3], T (&y_)[PPL][3], double& ys_) {
             int slot = newest - age;
             if (slot < 0) slot += m;
-            const HPair<T> h = hl[slot * ROW];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { s_[a] = h.s[a]; y_[a] = h.y[a]; }
+            for (int q = 0; q < PPL; ++q) {
+                const HPair<T> h = hl[q][slot * ROW];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { s_[q][a] = h.s[a]; y_[q][a] = h.y[a]; }
+            }
             ys_ = ys_l[slot * TPB];
         };
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { Ps[0][a] = sv[a]; Py[0][a] = yv[a]; }
+        for (int q = 0; q < PPL; ++q)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { Ps[0][q][a] = sv[q][a]; Py[0][q][a] = yv[q][a]; }
         Pys[0] = ys;
 #pragma unroll
         for (int age = 1; age < kWin; ++age)
@@ -772,49 +867,56 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
         for (int age = 0; age < kMaxMem; ++age) {      // newest -> oldest, LB:1294-1303
             if (age < bound) {
                 const int w = age % kWin;
-                double al = group_sum1<GROUP>(dot3(Ps[w], d));
+                double al = group_sum1<GROUP>(dot_lane<T, PPL>(Ps[w], d));
                 al /= Pys[w];
-                al_l[age * TPB] = al;      // alpha_j parks in LDS at a static offset
-                const T na = Q.interior ? (T)(-al) : T(0);
+                al_l[age * TPB] = al;                  // alpha_j parks in LDS at a static offset
 #pragma unroll
-                for (int a = 0; a < 3; ++a) d[a] += na * Py[w][a];
+                for (int q = 0; q < PPL; ++q) {
+                    const T na = Q.interior[q] ? (T)(-al) : T(0);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) d[q][a] += na * Py[w][q][a];
+                }
                 if (age + kWin < kMaxMem && age + kWin < bound) fetch(age + kWin, Ps[w], Py[w], Pys[w]);
             }
         }
         {
             const T sc = (T)(ys / yy);  // LB:1305
 #pragma unroll
-            for (int a = 0; a < 3; ++a) d[a] *= sc;
+            for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) d[q][a] *= sc;
         }
         // the window now holds the ages [max(0, bound - kWin), bound)
 #pragma unroll
         for (int age = kMaxMem - 1; age >= 0; --age) {  // oldest -> newest, LB:1307-1316
             if (age < bound) {
                 const int w = age % kWin;
-                double beta = group_sum1<GROUP>(dot3(Py[w], d));
+                double beta = group_sum1<GROUP>(dot_lane<T, PPL>(Py[w], d));
                 beta /= Pys[w];
-                const T co = Q.interior ? (T)(al_l[age * TPB] - beta) : T(0);
+                const double cod = al_l[age * TPB] - beta;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) d[a] += co * Ps[w][a];
+                for (int q = 0; q < PPL; ++q) {
+                    const T co = Q.interior[q] ? (T)cod : T(0);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) d[q][a] += co * Ps[w][q][a];
+                }
                 if (age - kWin >= 0) fetch(age - kWin, Ps[w], Py[w], Pys[w]);
             }
         }
-        sums[4] = group_sum1<GROUP>(dot3(g, d));  // dginit of the next line search (LB:746)
+        sums[4] = group_sum1<GROUP>(dot_lane<T, PPL>(g, d));  // dginit of the next line search (LB:746)
         step = 1.0;  // LB:1321
     }
 
     // results.  On success / convergence / iteration cap the last evaluated point is x itself.
-    if (ret >= 0 || ret == LBERR_MAXIMUMITERATION) {
-        if (Q.has_pt) {
-            double* dst = A.ctrl + ((size_t)b * N + p) * 3;
-            dst[0] = (double)x[0]; dst[1] = (double)x[1]; dst[2] = (double)x[2];
+    if (ret >= 0 || ret == LBERR_MAXIMUMITERATION) store_points<T, PPL>(A, b, Q, x);
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        if (Q.interior[q] && A.out_x) {
+            double* dst = A.out_x + ((size_t)b * NI + (Q.p0 + q - 3)) * 3;
+            dst[0] = (double)x[q][0]; dst[1] = (double)x[q][1]; dst[2] = (double)x[q][2];
         }
     }
-    if (Q.interior && A.out_x) {
-        double* dst = A.out_x + ((size_t)b * NI + (p - 3)) * 3;
-        dst[0] = (double)x[0]; dst[1] = (double)x[1]; dst[2] = (double)x[2];
-    }
-    if (p == 0) {
+    if (lane % GROUP == 0) {
         if (A.out_status) A.out_status[b] = ret;
         if (A.out_fx) A.out_fx[b] = fx;
         if (A.out_iters) A.out_iters[b] = k;
@@ -829,6 +931,8 @@ size_t optimize_lds_bytes(int N, int m) {
     h = (h + 15) & ~(size_t)15;
     return h + 2 * (size_t)m * TPB * sizeof(double);
 }
+
+constexpr size_t kLdsPerWorkgroup = 160 * 1024;
 
 }  // namespace
 
@@ -867,43 +971,65 @@ DevConst make_dev_const(const vigo_params_t& P) {
     return K;
 }
 
-int launch_cost_grad(hipStream_t s, const SolveArgs& a, const DevConst& k, int precision) {
-    if (a.B <= 0) return hipSuccess;
-    const bool g32 = a.N <= 32;
-    const int tpb = g32 ? 2 : 1;
+// (GROUP, PPL) for N control points: 32 x 1 up to 32, then 64 x {1, 2, 4}
+static inline int shape_for(int N) { return N <= 32 ? 0 : (N <= 64 ? 1 : (N <= 128 ? 2 : 3)); }
+
+template <typename T>
+static int launch_cost_grad_t(hipStream_t s, const SolveArgs& a, const DevConst& k) {
+    const int shape = shape_for(a.N);
+    const int tpb = shape == 0 ? 2 : 1;
     dim3 grid((a.B + tpb - 1) / tpb), block(kWave);
-    if (precision == VIGO_PREC_F32) {
-        if (g32) hipLaunchKernelGGL((k_cost_grad<float, 32>), grid, block, 0, s, a, k);
-        else     hipLaunchKernelGGL((k_cost_grad<float, 64>), grid, block, 0, s, a, k);
-    } else {
-        if (g32) hipLaunchKernelGGL((k_cost_grad<double, 32>), grid, block, 0, s, a, k);
-        else     hipLaunchKernelGGL((k_cost_grad<double, 64>), grid, block, 0, s, a, k);
+    switch (shape) {
+        case 0: hipLaunchKernelGGL((k_cost_grad<T, 32, 1>), grid, block, 0, s, a, k); break;
+        case 1: hipLaunchKernelGGL((k_cost_grad<T, 64, 1>), grid, block, 0, s, a, k); break;
+        case 2: hipLaunchKernelGGL((k_cost_grad<T, 64, 2>), grid, block, 0, s, a, k); break;
+        default: hipLaunchKernelGGL((k_cost_grad<T, 64, 4>), grid, block, 0, s, a, k); break;
     }
     return (int)hipGetLastError();
 }
 
-template <typename T, int GROUP>
+int launch_cost_grad(hipStream_t s, const SolveArgs& a, const DevConst& k, int precision) {
+    if (a.B <= 0) return hipSuccess;
+    return precision == VIGO_PREC_F32 ? launch_cost_grad_t<float>(s, a, k) : launch_cost_grad_t<double>(s, a, k);
+}
+
+template <typename T, int GROUP, int PPL>
 static int launch_optimize_t(hipStream_t s, const SolveArgs& a, const DevConst& k) {
     const int tpb = kWave / GROUP;
     const size_t lds = optimize_lds_bytes<T, GROUP>(a.N, k.mem_size);
+    if (lds > kLdsPerWorkgroup) return (int)hipErrorInvalidValue;  // refused earlier by vigo_optimize
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_optimize<T, GROUP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_optimize<T, GROUP, PPL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerWorkgroup);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid((a.B + tpb - 1) / tpb), block(kWave);
-    hipLaunchKernelGGL((k_optimize<T, GROUP>), grid, block, lds, s, a, k);
+    hipLaunchKernelGGL((k_optimize<T, GROUP, PPL>), grid, block, lds, s, a, k);
     return (int)hipGetLastError();
+}
+
+template <typename T>
+static int launch_optimize_p(hipStream_t s, const SolveArgs& a, const DevConst& k) {
+    switch (shape_for(a.N)) {
+        case 0: return launch_optimize_t<T, 32, 1>(s, a, k);
+        case 1: return launch_optimize_t<T, 64, 1>(s, a, k);
+        case 2: return launch_optimize_t<T, 64, 2>(s, a, k);
+        default: return launch_optimize_t<T, 64, 4>(s, a, k);
+    }
 }
 
 int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, int precision) {
     if (a.B <= 0) return hipSuccess;
-    const bool g32 = a.N <= 32;
-    if (precision == VIGO_PREC_F32)
-        return g32 ? launch_optimize_t<float, 32>(s, a, k) : launch_optimize_t<float, 64>(s, a, k);
-    return g32 ? launch_optimize_t<double, 32>(s, a, k) : launch_optimize_t<double, 64>(s, a, k);
+    return precision == VIGO_PREC_F32 ? launch_optimize_p<float>(s, a, k) : launch_optimize_p<double>(s, a, k);
+}
+
+// bytes of LDS one trajectory-solve workgroup needs; the C ABI refuses N it cannot hold
+size_t optimize_lds_requirement(int N, int mem_size, int precision) {
+    const bool g32 = N <= 32;
+    if (precision == VIGO_PREC_F32) return g32 ? optimize_lds_bytes<float, 32>(N, mem_size) : optimize_lds_bytes<float, 64>(N, mem_size);
+    return g32 ? optimize_lds_bytes<double, 32>(N, mem_size) : optimize_lds_bytes<double, 64>(N, mem_size);
 }
 
 }  // namespace vigo
