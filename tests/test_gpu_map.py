@@ -33,8 +33,13 @@ def test_point_queries_and_packing(vigo_handle, small_world):
     set_world(v, w2)
     out = v.query_points(to_dev(pts, v.device), 0).cpu().numpy()
     assert np.array_equal(out, synth.lookup(w2, pts, 0))
-    # packed snapshot round trip (the RCCL broadcast path)
+    # packed snapshot round trip (the RCCL broadcast path); the numpy statement of the format
+    # (used by the CPU gloo test) is pinned to the kernel here
     packed = v.pack_grid(to_dev(small_world.voxels, v.device))
+    from trajectory_planner_amd import sharding
+    assert np.array_equal(packed.cpu().numpy(), sharding.pack_grid_reference(small_world.voxels))
+    odd = np.ascontiguousarray(small_world.voxels[:33, :17, :41])
+    assert np.array_equal(v.pack_grid(to_dev(odd, v.device)).cpu().numpy(), sharding.pack_grid_reference(odd))
     v2 = Vigo(0)
     v2.set_grid_packed(packed, small_world.voxels.shape, small_world.origin, small_world.res)
     assert np.array_equal(v2.query_points(to_dev(pts, v.device), 1).cpu().numpy(), synth.lookup(small_world, pts, 1))

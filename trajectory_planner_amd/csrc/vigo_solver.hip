@@ -386,17 +386,18 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
                     const T dx = c[q][0] - px, dy = c[q][1] - py, dz = T(0.0);
                     const T nrm = sqrt((dx * dx + dy * dy) + dz * dz);
                     const T e = thr - (nrm - size);
-                    const T gx = dx / nrm, gy = dy / nrm, gz = dz / nrm;
+                    // grad = diff / |diff| (BT.cpp:1025) is only consumed by the two penalty
+                    // branches: the three fp64 divisions are issued there, not for every far step
                     if (e <= T(0)) {
                         // no punishment
                     } else if (e > T(0) && e <= thr) {
                         co += (double)((e * e) * e);
                         const T k = T(-3.0) * (e * e);
-                        Go[q][0] += k * gx; Go[q][1] += k * gy; Go[q][2] += k * gz;
+                        Go[q][0] += k * (dx / nrm); Go[q][1] += k * (dy / nrm); Go[q][2] += k * (dz / nrm);
                     } else if (e >= thr) {
                         co += (double)((oa * (e * e) + ob * e) + oc);
                         const T k = -((T(2) * oa) * e + ob);
-                        Go[q][0] += k * gx; Go[q][1] += k * gy; Go[q][2] += k * gz;
+                        Go[q][0] += k * (dx / nrm); Go[q][1] += k * (dy / nrm); Go[q][2] += k * (dz / nrm);
                     }
                 }
             }
