@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--workload", default="config2", choices=["config2", "config4"])
     ap.add_argument("--batch", type=int, default=0, help="override trajectories per GPU")
     ap.add_argument("--iters", type=int, default=50, help="L-BFGS max_iterations (BASELINE: 50)")
-    ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32", "f64_fast"],
+                    help="f64: reference expression order (default); f64_fast: explicit fma + reciprocal "
+                         "two-loop (VIGO_PREC_F64_FAST, same 1e-4 parity gate); f32: fp32 state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -150,7 +152,7 @@ def main():
     world, batch, wname = workload(args, rank, world_size)
     P = default_params()
     P.max_iterations = args.iters
-    v = Vigo(local_rank, P, PREC_F32 if args.precision == "f32" else PREC_F64)
+    v = Vigo(local_rank, P, {"f32": PREC_F32, "f64": PREC_F64, "f64_fast": 2}[args.precision])
     v.use_current_stream()
 
     # ---- voxel snapshot: rank 0 packs, one RCCL broadcast over xGMI, every rank adopts it ----
@@ -239,7 +241,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": args.precision,
+            "dtype": "f32" if args.precision == "f32" else "f64",
+            "arithmetic": args.precision,
             "data": "synthetic (seeded straight paths + box world, SURVEY.md §8d; no dataset exists for this path)",
             "config": {"workload": wname, "trajs_per_gpu": B, "ctrl_pts": N, "lbfgs_iters": args.iters,
                        "mem_size": int(P.mem_size), "g_epsilon": float(P.g_epsilon), "grid": list(dims),

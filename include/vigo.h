@@ -64,7 +64,11 @@ enum { VIGO_MAX_CTRL_POINTS = 256, VIGO_MAX_MEM_SIZE = 16 };
 /* arithmetic mode of the solver / cost kernels */
 typedef enum {
     VIGO_PREC_F64 = 0,       /* fp64 state + reductions (parity-gated default)        */
-    VIGO_PREC_F32 = 1        /* fp32 state, fp64 reductions (throughput mode)         */
+    VIGO_PREC_F32 = 1,       /* fp32 state, fp64 reductions (throughput mode)         */
+    VIGO_PREC_F64_FAST = 2   /* fp64 with fused multiply-adds in dot products / axpys /
+                                stencils (what GCC's default contraction does to the
+                                reference on ARM) and one reciprocal per history pair
+                                instead of a division per two-loop step; same 1e-4 gate  */
 } vigo_precision_t;
 
 /*

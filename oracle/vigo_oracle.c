@@ -28,6 +28,10 @@
 /* ------------------------------------------------------------------------------------ */
 static int g_emu_group = 0;
 static int g_emu_ppl = 1;   /* consecutive control points owned by one lane */
+static int g_emu_fast = 0;  /* mirror VIGO_PREC_F64_FAST: the kernels' explicit fma()s and the
+                               reciprocal-multiply of the two-loop recursion */
+void vgo_set_emulation_fast(int on) { g_emu_fast = on; }
+#define FAST (g_emu_group && g_emu_fast)
 void vgo_set_emulation(int group) { g_emu_group = group; g_emu_ppl = 1; }
 void vgo_set_emulation2(int group, int ppl) { g_emu_group = group; g_emu_ppl = ppl > 0 ? ppl : 1; }
 int vgo_get_emulation(void) { return g_emu_group; }
@@ -158,7 +162,8 @@ static double distance_term(const vigo_params_t* P, int N, const double* c, cons
         for (int32_t j = goff[i]; j < goff[i + 1]; ++j) {
             const double* p = gpv + 6 * (size_t)j;
             const double* v = p + 3;
-            double dist = sum3((ci[0] - p[0]) * v[0], (ci[1] - p[1]) * v[1], (ci[2] - p[2]) * v[2]);
+            double dist = FAST ? fma(ci[2] - p[2], v[2], fma(ci[1] - p[1], v[1], (ci[0] - p[0]) * v[0]))
+                               : sum3((ci[0] - p[0]) * v[0], (ci[1] - p[1]) * v[1], (ci[2] - p[2]) * v[2]);
             int unknown = gunk ? (gunk[j] != 0) : 0;
             double e = dth - dist;
             double ct, k, gt[3];
@@ -222,14 +227,20 @@ static double smoothness_term(int N, const double* c, double* G, double* lanes) 
     for (int i = 0; i < N - 3; ++i) {
         double jk[3], gt[3];
         for (int a = 0; a < 3; ++a) {
-            jk[a] = ((c[3 * (i + 3) + a] - 3 * c[3 * (i + 2) + a]) + 3 * c[3 * (i + 1) + a]) - c[3 * i + a];
+            jk[a] = FAST ? fma(3.0, c[3 * (i + 1) + a], fma(-3.0, c[3 * (i + 2) + a], c[3 * (i + 3) + a])) - c[3 * i + a]
+                         : ((c[3 * (i + 3) + a] - 3 * c[3 * (i + 2) + a]) + 3 * c[3 * (i + 1) + a]) - c[3 * i + a];
         }
         LANE_ADD(i, sum3(jk[0] * jk[0], jk[1] * jk[1], jk[2] * jk[2]));
         for (int a = 0; a < 3; ++a) gt[a] = 2.0 * jk[a];
         for (int a = 0; a < 3; ++a) {
             G[3 * i + a] += -gt[a];
-            G[3 * (i + 1) + a] += 3.0 * gt[a];
-            G[3 * (i + 2) + a] += -3.0 * gt[a];
+            if (FAST) {
+                G[3 * (i + 1) + a] = fma(3.0, gt[a], G[3 * (i + 1) + a]);
+                G[3 * (i + 2) + a] = fma(-3.0, gt[a], G[3 * (i + 2) + a]);
+            } else {
+                G[3 * (i + 1) + a] += 3.0 * gt[a];
+                G[3 * (i + 2) + a] += -3.0 * gt[a];
+            }
             G[3 * (i + 3) + a] += gt[a];
         }
     }
@@ -258,7 +269,8 @@ static double feasibility_term(const vigo_params_t* P, int N, const double* c, d
     }
     for (int i = 0; i < N - 2; ++i) {
         for (int j = 0; j < 3; ++j) {
-            double ai = ((c[3 * (i + 2) + j] - 2 * c[3 * (i + 1) + j]) + c[3 * i + j]) * tsInvSqr;
+            double ai = (FAST ? fma(-2.0, c[3 * (i + 1) + j], c[3 * (i + 2) + j]) + c[3 * i + j]
+                              : (c[3 * (i + 2) + j] - 2 * c[3 * (i + 1) + j]) + c[3 * i + j]) * tsInvSqr;
             if (ai > maxAcc) {
                 LANE_ADD(i, P2(ai - maxAcc));
                 G[3 * i + j] += 2 * (ai - maxAcc) * tsInvSqr;
@@ -340,7 +352,8 @@ double vgo_cost_grad(const vigo_params_t* P, int N, const double* ctrl, const in
     double co = dynamic_term(P, N, ctrl, n_obs, obs, Go, emu ? L[3] : NULL);
     double total = w[0] * cd + w[1] * cs + w[2] * cf + w[3] * co;
     for (int e = 0; e < 3 * N; ++e) {
-        double t = w[0] * Gd[e] + w[1] * Gs[e] + w[2] * Gf[e] + w[3] * Go[e];
+        double t = FAST ? fma(w[3], Go[e], fma(w[2], Gf[e], fma(w[1], Gs[e], w[0] * Gd[e])))
+                        : w[0] * Gd[e] + w[1] * Gs[e] + w[2] * Gf[e] + w[3] * Go[e];
         if (grad_full) grad_full[e] = t;
         if (grad_free && e >= 9 && e < 3 * (N - 3)) grad_free[e - 9] = t;
     }
@@ -368,7 +381,8 @@ static double dotn(const double* a, const double* b, int n) {
         double pts[VIGO_MAX_CTRL_POINTS];
         memset(pts, 0, sizeof(pts));
         for (int i = 0; i < n / 3; ++i)
-            pts[i + 3] = sum3(a[3 * i] * b[3 * i], a[3 * i + 1] * b[3 * i + 1], a[3 * i + 2] * b[3 * i + 2]);
+            pts[i + 3] = FAST ? fma(a[3 * i + 2], b[3 * i + 2], fma(a[3 * i + 1], b[3 * i + 1], a[3 * i] * b[3 * i]))
+                              : sum3(a[3 * i] * b[3 * i], a[3 * i + 1] * b[3 * i + 1], a[3 * i + 2] * b[3 * i + 2]);
         return lane_tree_sum(pts, g_emu_group);
     }
     double s = 0.;
@@ -530,8 +544,12 @@ static int more_thuente(ls_env* E, double* x, double* f, double* g, const double
             *stp = X.t;
         }
 
-        for (int i = 0; i < n; ++i) x[i] = xp[i];
-        for (int i = 0; i < n; ++i) x[i] += *stp * s[i];
+        if (FAST) {
+            for (int i = 0; i < n; ++i) x[i] = fma(*stp, s[i], xp[i]);
+        } else {
+            for (int i = 0; i < n; ++i) x[i] = xp[i];
+            for (int i = 0; i < n; ++i) x[i] += *stp * s[i];
+        }
 
         *f = E->eval(E->ctx, x, g, n);
         ++E->evals;
@@ -656,7 +674,7 @@ int vgo_lbfgs(int n, double* x, double* fx_out, vgo_eval_fn eval, void* ctx,
             for (int i = 0; i < n; ++i) yv[i] = g[i] - gp[i];
             double ys = dotn(yv, sv, n);
             double yy = dotn(yv, yv, n);
-            ysv[end] = ys;
+            ysv[end] = FAST ? 1.0 / ys : ys;   /* FAST keeps the reciprocal of ys */
 
             int bound = (m <= k) ? m : k;
             ++k;
@@ -669,9 +687,10 @@ int vgo_lbfgs(int n, double* x, double* fx_out, vgo_eval_fn eval, void* ctx,
                 const double* sj = S + (size_t)j * n;
                 const double* yj = Y + (size_t)j * n;
                 alpha[j] = dotn(sj, d, n);
-                alpha[j] /= ysv[j];
+                if (FAST) alpha[j] *= ysv[j]; else alpha[j] /= ysv[j];
                 double na = -alpha[j];
-                for (int e = 0; e < n; ++e) d[e] += na * yj[e];
+                if (FAST) { for (int e = 0; e < n; ++e) d[e] = fma(na, yj[e], d[e]); }
+                else      { for (int e = 0; e < n; ++e) d[e] += na * yj[e]; }
             }
             double sc = ys / yy;
             for (int e = 0; e < n; ++e) d[e] *= sc;
@@ -679,9 +698,10 @@ int vgo_lbfgs(int n, double* x, double* fx_out, vgo_eval_fn eval, void* ctx,
                 const double* sj = S + (size_t)j * n;
                 const double* yj = Y + (size_t)j * n;
                 double beta = dotn(yj, d, n);
-                beta /= ysv[j];
+                if (FAST) beta *= ysv[j]; else beta /= ysv[j];
                 double co = alpha[j] - beta;
-                for (int e = 0; e < n; ++e) d[e] += co * sj[e];
+                if (FAST) { for (int e = 0; e < n; ++e) d[e] = fma(co, sj[e], d[e]); }
+                else      { for (int e = 0; e < n; ++e) d[e] += co * sj[e]; }
                 j = (j + 1) % m;
             }
             step = 1.0;

@@ -36,6 +36,8 @@ void vgo_default_params(vigo_params_t* p);
  * pow-free powers so results can be compared with the GPU bit for bit (vigo_oracle.c top). */
 void vgo_set_emulation(int group);
 void vgo_set_emulation2(int group, int points_per_lane);
+/* with emulation on: also mirror VIGO_PREC_F64_FAST (explicit fma, reciprocal-multiply) */
+void vgo_set_emulation_fast(int on);
 int vgo_get_emulation(void);
 
 /* dense voxel map, same contract as vigo_set_grid (include/vigo.h) */

@@ -221,3 +221,34 @@ def test_fp32_mode_cost_and_statistics(vigo_handle, small_world):
     assert np.median(rel) < 5e-2 and np.isfinite(r.ctrl.cpu().numpy()).all()
     assert (r.fx.cpu().numpy() <= cr * (1 + 1e-5) + 1e-6).all()
     v.set_precision(PREC_F64)
+
+
+@pytest.mark.parametrize("N,B,n_obs", [(32, 300, 0), (20, 64, 2), (64, 40, 1), (100, 12, 0)])
+def test_fast_mode_matches_its_emulation_and_the_reference_gate(vigo_handle, small_world, N, B, n_obs):
+    """VIGO_PREC_F64_FAST (explicit fma + one reciprocal per history pair): bit-exact against the
+    oracle's fast emulation, and inside the same 1e-4 gate against the reference-order oracle."""
+    from trajectory_planner_amd.vigo import PREC_F64_FAST
+    v = vigo_handle
+    P = default_params()
+    P.max_iterations = 50
+    v.set_params(P)
+    v.set_precision(PREC_F64_FAST)
+    b = synth.make_bspline_batch(small_world, B, N, 777 + N, start_range=3.0, n_obs=n_obs)
+    d = batch_to_dev(b, v.device)
+    cost, grad, terms = v.cost_grad(**d)
+    r = v.optimize(**d)
+    ol.oracle().vgo_set_emulation_fast(1)
+    try:
+        with emulation(N):
+            ce, ge, te = ol.cost_grad_batch(P, b)
+            e = ol.optimize_batch(P, b)
+    finally:
+        ol.oracle().vgo_set_emulation_fast(0)
+    assert np.array_equal(cost.cpu().numpy(), ce) and np.array_equal(grad.cpu().numpy(), ge)
+    for k in ("status", "iters", "evals", "x", "ctrl", "fx"):
+        assert np.array_equal(getattr(r, k).cpu().numpy(), e[k]), f"{k} differs from the fast-emulation oracle"
+    ref = ol.optimize_batch(P, b)
+    rel = rel_err_per_traj(r.ctrl.cpu().numpy(), ref["ctrl"])
+    print(f"\n[fast N={N}] vs reference-order oracle: median {np.median(rel):.2e} p99 {np.quantile(rel, .99):.2e} max {rel.max():.2e}")
+    assert (rel <= TOL).mean() >= 0.99 and np.median(rel) < 1e-8
+    v.set_precision(PREC_F64)

@@ -164,3 +164,19 @@ def test_emulation_mode_is_a_rounding_level_change(small_world):
     rel = np.abs(r1["ctrl"] - r0["ctrl"]).reshape(b.B, -1).max(1) / np.abs(r0["ctrl"]).reshape(b.B, -1).max(1)
     assert np.median(rel) < 1e-9
     assert (rel <= 1e-4).mean() >= 0.99
+
+
+def test_fast_emulation_is_also_a_rounding_level_change(small_world):
+    b = synth.make_bspline_batch(small_world, 256, 32, 78, start_range=3.0, n_obs=1)
+    P = ol.default_params()
+    P.max_iterations = 50
+    r0 = ol.optimize_batch(P, b)
+    ol.set_emulation(32)
+    ol.oracle().vgo_set_emulation_fast(1)
+    try:
+        r1 = ol.optimize_batch(P, b)
+    finally:
+        ol.oracle().vgo_set_emulation_fast(0)
+        ol.set_emulation(0)
+    rel = np.abs(r1["ctrl"] - r0["ctrl"]).reshape(b.B, -1).max(1) / np.abs(r0["ctrl"]).reshape(b.B, -1).max(1)
+    assert np.median(rel) < 1e-9 and (rel <= 1e-4).mean() >= 0.99

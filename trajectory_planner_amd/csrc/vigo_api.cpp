@@ -196,7 +196,7 @@ int vigo_get_params(vigo_handle_t h, vigo_params_t* p) {
 
 int vigo_set_precision(vigo_handle_t h, int precision) {
     if (!h) return VIGO_ERR_INVALID_ARG;
-    if (precision != VIGO_PREC_F64 && precision != VIGO_PREC_F32) return fail(h, VIGO_ERR_INVALID_ARG, "unknown precision");
+    if (precision != VIGO_PREC_F64 && precision != VIGO_PREC_F32 && precision != VIGO_PREC_F64_FAST) return fail(h, VIGO_ERR_INVALID_ARG, "unknown precision");
     h->precision = precision;
     return VIGO_OK;
 }

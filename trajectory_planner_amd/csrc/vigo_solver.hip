@@ -158,16 +158,25 @@ __device__ __forceinline__ double group_sum1(double v) {
 
 __device__ __forceinline__ double sum3(double a, double b, double c) { return (a + b) + c; }
 
-template <typename T>
+// FAST (VIGO_PREC_F64_FAST): explicit fused multiply-adds in the dot products, axpys, stencils
+// and the weight combination — what GCC's default -ffp-contract=fast does to the reference on
+// its ARM targets — plus one reciprocal per history pair instead of a division per two-loop
+// step.  Every fma below is mirrored by oracle/vigo_oracle.c's fast emulation, bit for bit.
+__device__ __forceinline__ double fmaT(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fmaT(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <bool FAST, typename T>
 __device__ __forceinline__ double dot3(const T (&a)[3], const T (&b)[3]) {
+    if (FAST)
+        return fmaT((double)a[2], (double)b[2], fmaT((double)a[1], (double)b[1], (double)a[0] * (double)b[0]));
     return sum3((double)a[0] * (double)b[0], (double)a[1] * (double)b[1], (double)a[2] * (double)b[2]);
 }
 // lane partial of a dot product: the lane's points in index order, starting from 0
-template <typename T, int PPL>
+template <bool FAST, typename T, int PPL>
 __device__ __forceinline__ double dot_lane(const T (&a)[PPL][3], const T (&b)[PPL][3]) {
     double s = 0.0;
 #pragma unroll
-    for (int q = 0; q < PPL; ++q) s += dot3(a[q], b[q]);
+    for (int q = 0; q < PPL; ++q) s += dot3<FAST, T>(a[q], b[q]);
     return s;
 }
 
@@ -201,11 +210,12 @@ struct LaneProblem {
 
 // One guide pair's contribution, BT.cpp:839-895.  e == dthresh takes the cubic branch (first
 // else-if wins); the "too far" branch is never scaled by the unknown factor.
-template <typename T>
+template <bool FAST, typename T>
 __device__ __forceinline__ void guide_pair_term(const DevConst& K, const T (&c)[3], T px, T py, T pz, T vx,
                                                 T vy, T vz, bool unk, double& cd, T (&Gd)[3]) {
     const T dth = (T)K.dth, da = (T)K.da, db = (T)K.db, dcc = (T)K.dc, uf = (T)K.unc_factor;
-    const T dist = ((c[0] - px) * vx + (c[1] - py) * vy) + (c[2] - pz) * vz;
+    const T dist = FAST ? fmaT(c[2] - pz, vz, fmaT(c[1] - py, vy, (c[0] - px) * vx))
+                        : ((c[0] - px) * vx + (c[1] - py) * vy) + (c[2] - pz) * vz;
     const T e = dth - dist;
     T ct, k;
     bool scale = false;
@@ -239,7 +249,7 @@ __device__ __forceinline__ void guide_pair_term(const DevConst& K, const T (&c)[
 // (the line search needs g.d after every evaluation, LB:829, and the norms after the last one,
 // LB:1200-1201; fusing them costs three more DPP chains instead of two more reductions).
 // Returns the weighted total cost (group-uniform).
-template <typename T, int GROUP, int PPL>
+template <typename T, int GROUP, int PPL, bool FAST>
 __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LaneProblem<T, PPL>& Q,
                                                  const T (&c)[PPL][3], const T (&d)[PPL][3], T (&g)[PPL][3],
                                                  double (&sums)[7]) {
@@ -275,12 +285,14 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
                 // smoothness, BT.cpp:934-950
-                const T J0 = ((P3[q] - 3 * P2[q]) + 3 * P1[q]) - C[q];
+                const T J0 = FAST ? fmaT(T(3), P1[q], fmaT(T(-3), P2[q], P3[q])) - C[q]
+                                  : ((P3[q] - 3 * P2[q]) + 3 * P1[q]) - C[q];
                 gt0[q] = T(2.0) * J0;                                          // gradTemp
                 jj[q][a] = (double)(J0 * J0);
                 // feasibility, BT.cpp:952-999 (limits hard-coded to 1.0, :955-956)
                 const T evP = excess((P1[q] - C[q]) / ts);                     // velocity i
-                const T eaP = excess(((P2[q] - 2 * P1[q]) + C[q]) * tis);      // acceleration i
+                const T eaP = excess((FAST ? fmaT(T(-2), P1[q], P2[q]) + C[q]
+                                           : (P2[q] - 2 * P1[q]) + C[q]) * tis);   // acceleration i
                 // gradient(j,i+1) += 2(v-vmax)/ts*tsInvSqr, gradient(j,i) += the negation (exactly)
                 gv[q] = (T(2) * evP) / ts * tis;
                 // gradient(j,i), (j,i+2) += 2(a-amax)*tsInvSqr; gradient(j,i+1) += -4(..) = -2x that (exactly)
@@ -298,8 +310,13 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
                 T acc = gt3[q];                    // i-3: col(i+3) += gradTemp
-                acc += T(-3.0) * gt2[q];           // i-2: col(i+2) += -3*gradTemp
-                acc += T(3.0) * gt1[q];            // i-1: col(i+1) += 3*gradTemp
+                if (FAST) {
+                    acc = fmaT(T(-3.0), gt2[q], acc);
+                    acc = fmaT(T(3.0), gt1[q], acc);
+                } else {
+                    acc += T(-3.0) * gt2[q];       // i-2: col(i+2) += -3*gradTemp
+                    acc += T(3.0) * gt1[q];        // i-1: col(i+1) += 3*gradTemp
+                }
                 acc += -gt0[q];                    // i  : col(i)   += -gradTemp
                 Gs[q][a] = acc;
                 T fcc = gvM[q];                    // i-1: gradient(j,i+1)
@@ -331,12 +348,12 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
 #pragma unroll
             for (int j = 0; j < LP::kGuideRegs; ++j) {
                 if (j < cnt)
-                    guide_pair_term<T>(K, c[q], Q.gq[j][0], Q.gq[j][1], Q.gq[j][2], Q.gq[j][3], Q.gq[j][4], Q.gq[j][5],
+                    guide_pair_term<FAST, T>(K, c[q], Q.gq[j][0], Q.gq[j][1], Q.gq[j][2], Q.gq[j][3], Q.gq[j][4], Q.gq[j][5],
                                        Q.gqu[j], cd, Gd[q]);
             }
             for (int j = Q.g_begin[q] + LP::kGuideRegs; j < Q.g_end[q]; ++j) {
                 const double* pv = Q.gpv + 6 * (size_t)j;
-                guide_pair_term<T>(K, c[q], (T)pv[0], (T)pv[1], (T)pv[2], (T)pv[3], (T)pv[4], (T)pv[5],
+                guide_pair_term<FAST, T>(K, c[q], (T)pv[0], (T)pv[1], (T)pv[2], (T)pv[3], (T)pv[4], (T)pv[5],
                                    Q.gunk ? (Q.gunk[j] != 0) : false, cd, Gd[q]);
             }
             if (K.plan_in_z) {
@@ -411,14 +428,16 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
     for (int q = 0; q < PPL; ++q) {
 #pragma unroll
         for (int a = 0; a < 3; ++a)
-            g[q][a] = Q.interior[q] ? (((w0 * Gd[q][a] + w1 * Gs[q][a]) + w2 * Gf[q][a]) + w3 * Go[q][a]) : T(0);
+            g[q][a] = !Q.interior[q] ? T(0)
+                      : (FAST ? fmaT(w3, Go[q][a], fmaT(w2, Gf[q][a], fmaT(w1, Gs[q][a], w0 * Gd[q][a])))
+                              : ((w0 * Gd[q][a] + w1 * Gs[q][a]) + w2 * Gf[q][a]) + w3 * Go[q][a]);
         part[0] += pt_d[q];
         part[1] += pt_s[q];
         part[2] += pt_f[q];
         part[3] += pt_o[q];
-        part[4] += dot3(g[q], d[q]);
-        part[5] += Q.interior[q] ? dot3(c[q], c[q]) : 0.0;
-        part[6] += dot3(g[q], g[q]);
+        part[4] += dot3<FAST, T>(g[q], d[q]);
+        part[5] += Q.interior[q] ? dot3<FAST, T>(c[q], c[q]) : 0.0;
+        part[6] += dot3<FAST, T>(g[q], g[q]);
     }
     group_sum<GROUP, 7>(part);
 #pragma unroll
@@ -499,7 +518,7 @@ __device__ __forceinline__ void store_points(const SolveArgs& A, int b, const La
 }
 
 // ---- standalone cost/gradient kernel (vigo_cost_grad) ----------------------------------
-template <typename T, int GROUP, int PPL>
+template <typename T, int GROUP, int PPL, bool FAST>
 __global__ void __launch_bounds__(kWave) k_cost_grad(SolveArgs A, DevConst K) {
     constexpr int TPB = kWave / GROUP;
     const int lane = threadIdx.x;
@@ -512,7 +531,7 @@ __global__ void __launch_bounds__(kWave) k_cost_grad(SolveArgs A, DevConst K) {
 #pragma unroll
     for (int q = 0; q < PPL; ++q) zero[q][0] = zero[q][1] = zero[q][2] = T(0);
     double sums[7];
-    const double f = eval_cost_grad<T, GROUP, PPL>(K, Q, c, zero, g, sums);
+    const double f = eval_cost_grad<T, GROUP, PPL, FAST>(K, Q, c, zero, g, sums);
 #pragma unroll
     for (int q = 0; q < PPL; ++q) {
         if (Q.interior[q] && A.out_grad) {
@@ -649,7 +668,7 @@ __device__ __forceinline__ int trial_interval(double& xt, double& xf, double& xd
 #ifndef VIGO_TWOLOOP_WIN
 #define VIGO_TWOLOOP_WIN 2
 #endif
-template <typename T, int GROUP, int PPL>
+template <typename T, int GROUP, int PPL, bool FAST>
 __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) {
     constexpr int TPB = kWave / GROUP;
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -737,10 +756,11 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
 #pragma unroll
                 for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) x[q][a] = xp[q][a] + (T)step * d[q][a];
+                    for (int a = 0; a < 3; ++a)
+                        x[q][a] = FAST ? fmaT((T)step, d[q][a], xp[q][a]) : xp[q][a] + (T)step * d[q][a];
             }
 
-            fx = eval_cost_grad<T, GROUP, PPL>(K, Q, x, d, g, sums);  // the only evaluation site (LB:828, :1132)
+            fx = eval_cost_grad<T, GROUP, PPL, FAST>(K, Q, x, d, g, sums);  // the only evaluation site (LB:828, :1132)
             ++evals;
             if (first) break;
 
@@ -824,10 +844,12 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
                 hl[q][end * ROW] = hp;
             }
         }
-        double ysyy[2] = {dot_lane<T, PPL>(yv, sv), dot_lane<T, PPL>(yv, yv)};
+        double ysyy[2] = {dot_lane<FAST, T, PPL>(yv, sv), dot_lane<FAST, T, PPL>(yv, yv)};
         group_sum<GROUP, 2>(ysyy);
         const double ys = ysyy[0], yy = ysyy[1];
-        ys_l[end * TPB] = ys;
+        // the two-loop divides by ys of each pair (LB:1300, :1312); FAST keeps its reciprocal instead
+        const double ys_div = FAST ? 1.0 / ys : ys;
+        ys_l[end * TPB] = ys_div;
 
         // two-loop recursion, LB:1286-1316, fully unrolled over the pair's age with a register
         // window of kWin pairs (static index age % kWin): the pair needed kWin steps ahead is
@@ -860,7 +882,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
         for (int q = 0; q < PPL; ++q)
 #pragma unroll
             for (int a = 0; a < 3; ++a) { Ps[0][q][a] = sv[q][a]; Py[0][q][a] = yv[q][a]; }
-        Pys[0] = ys;
+        Pys[0] = ys_div;
 #pragma unroll
         for (int age = 1; age < kWin; ++age)
             if (age < bound) fetch(age, Ps[age], Py[age], Pys[age]);
@@ -868,14 +890,14 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
         for (int age = 0; age < kMaxMem; ++age) {      // newest -> oldest, LB:1294-1303
             if (age < bound) {
                 const int w = age % kWin;
-                double al = group_sum1<GROUP>(dot_lane<T, PPL>(Ps[w], d));
-                al /= Pys[w];
+                double al = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(Ps[w], d));
+                if (FAST) al *= Pys[w]; else al /= Pys[w];
                 al_l[age * TPB] = al;                  // alpha_j parks in LDS at a static offset
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) {
                     const T na = Q.interior[q] ? (T)(-al) : T(0);
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) d[q][a] += na * Py[w][q][a];
+                    for (int a = 0; a < 3; ++a) d[q][a] = FAST ? fmaT(na, Py[w][q][a], d[q][a]) : d[q][a] + na * Py[w][q][a];
                 }
                 if (age + kWin < kMaxMem && age + kWin < bound) fetch(age + kWin, Ps[w], Py[w], Pys[w]);
             }
@@ -892,19 +914,19 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) 
         for (int age = kMaxMem - 1; age >= 0; --age) {  // oldest -> newest, LB:1307-1316
             if (age < bound) {
                 const int w = age % kWin;
-                double beta = group_sum1<GROUP>(dot_lane<T, PPL>(Py[w], d));
-                beta /= Pys[w];
+                double beta = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(Py[w], d));
+                if (FAST) beta *= Pys[w]; else beta /= Pys[w];
                 const double cod = al_l[age * TPB] - beta;
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) {
                     const T co = Q.interior[q] ? (T)cod : T(0);
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) d[q][a] += co * Ps[w][q][a];
+                    for (int a = 0; a < 3; ++a) d[q][a] = FAST ? fmaT(co, Ps[w][q][a], d[q][a]) : d[q][a] + co * Ps[w][q][a];
                 }
                 if (age - kWin >= 0) fetch(age - kWin, Ps[w], Py[w], Pys[w]);
             }
         }
-        sums[4] = group_sum1<GROUP>(dot_lane<T, PPL>(g, d));  // dginit of the next line search (LB:746)
+        sums[4] = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(g, d));  // dginit of the next line search (LB:746)
         step = 1.0;  // LB:1321
     }
 
@@ -975,55 +997,59 @@ DevConst make_dev_const(const vigo_params_t& P) {
 // (GROUP, PPL) for N control points: 32 x 1 up to 32, then 64 x {1, 2, 4}
 static inline int shape_for(int N) { return N <= 32 ? 0 : (N <= 64 ? 1 : (N <= 128 ? 2 : 3)); }
 
-template <typename T>
+template <typename T, bool FAST>
 static int launch_cost_grad_t(hipStream_t s, const SolveArgs& a, const DevConst& k) {
     const int shape = shape_for(a.N);
     const int tpb = shape == 0 ? 2 : 1;
     dim3 grid((a.B + tpb - 1) / tpb), block(kWave);
     switch (shape) {
-        case 0: hipLaunchKernelGGL((k_cost_grad<T, 32, 1>), grid, block, 0, s, a, k); break;
-        case 1: hipLaunchKernelGGL((k_cost_grad<T, 64, 1>), grid, block, 0, s, a, k); break;
-        case 2: hipLaunchKernelGGL((k_cost_grad<T, 64, 2>), grid, block, 0, s, a, k); break;
-        default: hipLaunchKernelGGL((k_cost_grad<T, 64, 4>), grid, block, 0, s, a, k); break;
+        case 0: hipLaunchKernelGGL((k_cost_grad<T, 32, 1, FAST>), grid, block, 0, s, a, k); break;
+        case 1: hipLaunchKernelGGL((k_cost_grad<T, 64, 1, FAST>), grid, block, 0, s, a, k); break;
+        case 2: hipLaunchKernelGGL((k_cost_grad<T, 64, 2, FAST>), grid, block, 0, s, a, k); break;
+        default: hipLaunchKernelGGL((k_cost_grad<T, 64, 4, FAST>), grid, block, 0, s, a, k); break;
     }
     return (int)hipGetLastError();
 }
 
 int launch_cost_grad(hipStream_t s, const SolveArgs& a, const DevConst& k, int precision) {
     if (a.B <= 0) return hipSuccess;
-    return precision == VIGO_PREC_F32 ? launch_cost_grad_t<float>(s, a, k) : launch_cost_grad_t<double>(s, a, k);
+    if (precision == VIGO_PREC_F32) return launch_cost_grad_t<float, false>(s, a, k);
+    if (precision == VIGO_PREC_F64_FAST) return launch_cost_grad_t<double, true>(s, a, k);
+    return launch_cost_grad_t<double, false>(s, a, k);
 }
 
-template <typename T, int GROUP, int PPL>
+template <typename T, int GROUP, int PPL, bool FAST>
 static int launch_optimize_t(hipStream_t s, const SolveArgs& a, const DevConst& k) {
     const int tpb = kWave / GROUP;
     const size_t lds = optimize_lds_bytes<T, GROUP>(a.N, k.mem_size);
     if (lds > kLdsPerWorkgroup) return (int)hipErrorInvalidValue;  // refused earlier by vigo_optimize
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_optimize<T, GROUP, PPL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_optimize<T, GROUP, PPL, FAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerWorkgroup);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid((a.B + tpb - 1) / tpb), block(kWave);
-    hipLaunchKernelGGL((k_optimize<T, GROUP, PPL>), grid, block, lds, s, a, k);
+    hipLaunchKernelGGL((k_optimize<T, GROUP, PPL, FAST>), grid, block, lds, s, a, k);
     return (int)hipGetLastError();
 }
 
-template <typename T>
+template <typename T, bool FAST>
 static int launch_optimize_p(hipStream_t s, const SolveArgs& a, const DevConst& k) {
     switch (shape_for(a.N)) {
-        case 0: return launch_optimize_t<T, 32, 1>(s, a, k);
-        case 1: return launch_optimize_t<T, 64, 1>(s, a, k);
-        case 2: return launch_optimize_t<T, 64, 2>(s, a, k);
-        default: return launch_optimize_t<T, 64, 4>(s, a, k);
+        case 0: return launch_optimize_t<T, 32, 1, FAST>(s, a, k);
+        case 1: return launch_optimize_t<T, 64, 1, FAST>(s, a, k);
+        case 2: return launch_optimize_t<T, 64, 2, FAST>(s, a, k);
+        default: return launch_optimize_t<T, 64, 4, FAST>(s, a, k);
     }
 }
 
 int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, int precision) {
     if (a.B <= 0) return hipSuccess;
-    return precision == VIGO_PREC_F32 ? launch_optimize_p<float>(s, a, k) : launch_optimize_p<double>(s, a, k);
+    if (precision == VIGO_PREC_F32) return launch_optimize_p<float, false>(s, a, k);
+    if (precision == VIGO_PREC_F64_FAST) return launch_optimize_p<double, true>(s, a, k);
+    return launch_optimize_p<double, false>(s, a, k);
 }
 
 // bytes of LDS one trajectory-solve workgroup needs; the C ABI refuses N it cannot hold

@@ -15,6 +15,7 @@ from ._lib import VigoParams
 
 PREC_F64 = 0
 PREC_F32 = 1
+PREC_F64_FAST = 2
 
 # lbfgs.hpp:20-80 status codes worth naming
 LBFGS_CONVERGENCE = 0
