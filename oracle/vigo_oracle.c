@@ -45,8 +45,8 @@ static inline double PHALF(double x) { return g_emu_group ? sqrt(x) : pow(x, 0.5
 static double lane_tree_sum(const double* pts, int group) {
     double a[64], b[64];
     for (int i = 0; i < group; ++i) {
-        double s = 0.0;
-        for (int q = 0; q < g_emu_ppl; ++q) s += pts[i * g_emu_ppl + q];
+        double s = pts[i * g_emu_ppl];
+        for (int q = 1; q < g_emu_ppl; ++q) s += pts[i * g_emu_ppl + q];
         a[i] = s;
     }
     for (int m = 1; m < group; m <<= 1) {

@@ -153,6 +153,11 @@ int vigo_create(vigo_handle_t* out, int device_ordinal) {
     h->device = device_ordinal;
     vigo_default_params(&h->params);
     h->dc = vigo::make_dev_const(h->params);
+    if (hipMalloc(reinterpret_cast<void**>(&h->dc_dev), sizeof(vigo::DevConst)) != hipSuccess ||
+        hipMemcpy(h->dc_dev, &h->dc, sizeof(vigo::DevConst), hipMemcpyHostToDevice) != hipSuccess) {
+        delete h;
+        return VIGO_ERR_HIP;
+    }
     *out = h;
     return VIGO_OK;
 }
@@ -163,6 +168,7 @@ int vigo_destroy(vigo_handle_t h) {
     if (h->grid_planes) (void)hipFree(h->grid_planes);
     if (h->esdf) (void)hipFree(h->esdf);
     if (h->scratch) (void)hipFree(h->scratch);
+    if (h->dc_dev) (void)hipFree(h->dc_dev);
     delete h;
     return VIGO_OK;
 }
@@ -185,6 +191,8 @@ int vigo_set_params(vigo_handle_t h, const vigo_params_t* p) {
         return fail(h, VIGO_ERR_INVALID_ARG, "invalid L-BFGS parameter (see lbfgs.hpp:1060-1104)");
     h->params = *p;
     h->dc = vigo::make_dev_const(h->params);
+    // blocking copy: every launch issued after this call sees the new constants, whatever its stream
+    VIGO_HIP(h, hipMemcpy(h->dc_dev, &h->dc, sizeof(vigo::DevConst), hipMemcpyHostToDevice));
     return VIGO_OK;
 }
 
@@ -283,7 +291,7 @@ int vigo_cost_grad(vigo_handle_t h, int B, int N, const double* ctrl, const int3
     a.obs_off = obs_off; a.obs = obs; a.n_obs_shared = n_obs_shared;
     a.weights = weights;
     a.out_cost = out_cost; a.out_grad = out_grad; a.out_terms = out_terms;
-    VIGO_HIP(h, (hipError_t)vigo::launch_cost_grad(h->stream, a, h->dc, h->precision));
+    VIGO_HIP(h, (hipError_t)vigo::launch_cost_grad(h->stream, a, h->dc, h->dc_dev, h->precision));
     return VIGO_OK;
 }
 
@@ -304,7 +312,7 @@ int vigo_optimize(vigo_handle_t h, int B, int N, double* ctrl, const int32_t* gu
     a.out_iters = out_iters; a.out_evals = out_evals;
     if (vigo::optimize_lds_requirement(N, h->params.mem_size, h->precision) > (size_t)160 * 1024)
         return fail(h, VIGO_ERR_UNSUPPORTED_N, "the L-BFGS history of N control points x mem_size does not fit the 160 KiB LDS of a CU");
-    VIGO_HIP(h, (hipError_t)vigo::launch_optimize(h->stream, a, h->dc, h->precision));
+    VIGO_HIP(h, (hipError_t)vigo::launch_optimize(h->stream, a, h->dc, h->dc_dev, h->precision));
     return VIGO_OK;
 }
 

@@ -75,8 +75,9 @@ struct EsdfView {
 };
 
 // launchers (each returns hipError_t as int)
-int launch_cost_grad(hipStream_t s, const SolveArgs& a, const DevConst& k, int precision);
-int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, int precision);
+// k: host copy (launch geometry), kd: the same constants in device memory (read by the kernels)
+int launch_cost_grad(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, int precision);
+int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, int precision);
 // LDS bytes one solve workgroup needs for N control points (must stay <= 160 KiB)
 size_t optimize_lds_requirement(int N, int mem_size, int precision);
 
@@ -108,6 +109,7 @@ struct vigo_context {
     hipStream_t stream = nullptr;
     vigo_params_t params;
     vigo::DevConst dc;
+    vigo::DevConst* dc_dev = nullptr;  // device copy, refreshed by vigo_set_params
     int precision = VIGO_PREC_F64;
     std::string last_error;
     // voxel snapshot

@@ -20,6 +20,8 @@
 // -ffp-contract=off so no FMA contraction changes a rounding.  Differences to the CPU
 // reference are confined to: summation order of the reductions above, x*x / x*x*x instead
 // of glibc pow(x,2|3), sqrt instead of pow(.,0.5).
+#include <stdlib.h>
+
 #include "vigo_internal.hpp"
 
 namespace vigo {
@@ -133,7 +135,7 @@ __device__ __forceinline__ double xor32_sum(double v) {
 }
 template <int GROUP, int K>
 __device__ __forceinline__ void group_sum(double (&v)[K]) {
-    static_assert(GROUP == 32 || GROUP == 64, "group is half a wave or a wave");
+    static_assert(GROUP == 16 || GROUP == 32 || GROUP == 64, "group is a DPP row, half a wave or a wave");
 #pragma unroll
     for (int q = 0; q < K; ++q) v[q] += dpp_f64<0xB1>(v[q]);   // quad_perm:[1,0,3,2]
 #pragma unroll
@@ -142,8 +144,10 @@ __device__ __forceinline__ void group_sum(double (&v)[K]) {
     for (int q = 0; q < K; ++q) v[q] += dpp_f64<0x141>(v[q]);  // row_half_mirror
 #pragma unroll
     for (int q = 0; q < K; ++q) v[q] += dpp_f64<0x140>(v[q]);  // row_mirror
+    if (GROUP >= 32) {
 #pragma unroll
-    for (int q = 0; q < K; ++q) v[q] = xor16_sum(v[q]);
+        for (int q = 0; q < K; ++q) v[q] = xor16_sum(v[q]);
+    }
     if (GROUP == 64) {
 #pragma unroll
         for (int q = 0; q < K; ++q) v[q] = xor32_sum(v[q]);
@@ -171,12 +175,12 @@ __device__ __forceinline__ double dot3(const T (&a)[3], const T (&b)[3]) {
         return fmaT((double)a[2], (double)b[2], fmaT((double)a[1], (double)b[1], (double)a[0] * (double)b[0]));
     return sum3((double)a[0] * (double)b[0], (double)a[1] * (double)b[1], (double)a[2] * (double)b[2]);
 }
-// lane partial of a dot product: the lane's points in index order, starting from 0
+// lane partial of a dot product: the lane's first point, then its other points in index order
 template <bool FAST, typename T, int PPL>
 __device__ __forceinline__ double dot_lane(const T (&a)[PPL][3], const T (&b)[PPL][3]) {
-    double s = 0.0;
+    double s = dot3<FAST, T>(a[0], b[0]);
 #pragma unroll
-    for (int q = 0; q < PPL; ++q) s += dot3<FAST, T>(a[q], b[q]);
+    for (int q = 1; q < PPL; ++q) s += dot3<FAST, T>(a[q], b[q]);
     return s;
 }
 
@@ -423,7 +427,7 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
     }
 
     const T w0 = (T)Q.w[0], w1 = (T)Q.w[1], w2 = (T)Q.w[2], w3 = (T)Q.w[3];
-    double part[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double part[7];  // lane partials: the lane's first point, then its other points in index order
 #pragma unroll
     for (int q = 0; q < PPL; ++q) {
 #pragma unroll
@@ -431,13 +435,16 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
             g[q][a] = !Q.interior[q] ? T(0)
                       : (FAST ? fmaT(w3, Go[q][a], fmaT(w2, Gf[q][a], fmaT(w1, Gs[q][a], w0 * Gd[q][a])))
                               : ((w0 * Gd[q][a] + w1 * Gs[q][a]) + w2 * Gf[q][a]) + w3 * Go[q][a]);
-        part[0] += pt_d[q];
-        part[1] += pt_s[q];
-        part[2] += pt_f[q];
-        part[3] += pt_o[q];
-        part[4] += dot3<FAST, T>(g[q], d[q]);
-        part[5] += Q.interior[q] ? dot3<FAST, T>(c[q], c[q]) : 0.0;
-        part[6] += dot3<FAST, T>(g[q], g[q]);
+        const double v4 = dot3<FAST, T>(g[q], d[q]);
+        const double v5 = Q.interior[q] ? dot3<FAST, T>(c[q], c[q]) : 0.0;
+        const double v6 = dot3<FAST, T>(g[q], g[q]);
+        if (q == 0) {
+            part[0] = pt_d[0]; part[1] = pt_s[0]; part[2] = pt_f[0]; part[3] = pt_o[0];
+            part[4] = v4; part[5] = v5; part[6] = v6;
+        } else {
+            part[0] += pt_d[q]; part[1] += pt_s[q]; part[2] += pt_f[q]; part[3] += pt_o[q];
+            part[4] += v4; part[5] += v5; part[6] += v6;
+        }
     }
     group_sum<GROUP, 7>(part);
 #pragma unroll
@@ -519,7 +526,8 @@ __device__ __forceinline__ void store_points(const SolveArgs& A, int b, const La
 
 // ---- standalone cost/gradient kernel (vigo_cost_grad) ----------------------------------
 template <typename T, int GROUP, int PPL, bool FAST>
-__global__ void __launch_bounds__(kWave) k_cost_grad(SolveArgs A, DevConst K) {
+__global__ void __launch_bounds__(kWave) k_cost_grad(SolveArgs A, const DevConst* __restrict__ Kp) {
+    const DevConst& K = *Kp;  // uniform address: scalar loads at the use sites, not 100+ live SGPRs
     constexpr int TPB = kWave / GROUP;
     const int lane = threadIdx.x;
     const int b = blockIdx.x * TPB + lane / GROUP;
@@ -669,7 +677,8 @@ __device__ __forceinline__ int trial_interval(double& xt, double& xf, double& xd
 #define VIGO_TWOLOOP_WIN 2
 #endif
 template <typename T, int GROUP, int PPL, bool FAST>
-__global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, DevConst K) {
+__global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevConst* __restrict__ Kp) {
+    const DevConst& K = *Kp;  // uniform address: scalar loads at the use sites, not 100+ live SGPRs
     constexpr int TPB = kWave / GROUP;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int N = A.N, NI = N - 6;
@@ -998,28 +1007,29 @@ DevConst make_dev_const(const vigo_params_t& P) {
 static inline int shape_for(int N) { return N <= 32 ? 0 : (N <= 64 ? 1 : (N <= 128 ? 2 : 3)); }
 
 template <typename T, bool FAST>
-static int launch_cost_grad_t(hipStream_t s, const SolveArgs& a, const DevConst& k) {
+static int launch_cost_grad_t(hipStream_t s, const SolveArgs& a, const DevConst* kd) {
     const int shape = shape_for(a.N);
     const int tpb = shape == 0 ? 2 : 1;
     dim3 grid((a.B + tpb - 1) / tpb), block(kWave);
     switch (shape) {
-        case 0: hipLaunchKernelGGL((k_cost_grad<T, 32, 1, FAST>), grid, block, 0, s, a, k); break;
-        case 1: hipLaunchKernelGGL((k_cost_grad<T, 64, 1, FAST>), grid, block, 0, s, a, k); break;
-        case 2: hipLaunchKernelGGL((k_cost_grad<T, 64, 2, FAST>), grid, block, 0, s, a, k); break;
-        default: hipLaunchKernelGGL((k_cost_grad<T, 64, 4, FAST>), grid, block, 0, s, a, k); break;
+        case 0: hipLaunchKernelGGL((k_cost_grad<T, 32, 1, FAST>), grid, block, 0, s, a, kd); break;
+        case 1: hipLaunchKernelGGL((k_cost_grad<T, 64, 1, FAST>), grid, block, 0, s, a, kd); break;
+        case 2: hipLaunchKernelGGL((k_cost_grad<T, 64, 2, FAST>), grid, block, 0, s, a, kd); break;
+        default: hipLaunchKernelGGL((k_cost_grad<T, 64, 4, FAST>), grid, block, 0, s, a, kd); break;
     }
     return (int)hipGetLastError();
 }
 
-int launch_cost_grad(hipStream_t s, const SolveArgs& a, const DevConst& k, int precision) {
+int launch_cost_grad(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, int precision) {
+    (void)k;
     if (a.B <= 0) return hipSuccess;
-    if (precision == VIGO_PREC_F32) return launch_cost_grad_t<float, false>(s, a, k);
-    if (precision == VIGO_PREC_F64_FAST) return launch_cost_grad_t<double, true>(s, a, k);
-    return launch_cost_grad_t<double, false>(s, a, k);
+    if (precision == VIGO_PREC_F32) return launch_cost_grad_t<float, false>(s, a, kd);
+    if (precision == VIGO_PREC_F64_FAST) return launch_cost_grad_t<double, true>(s, a, kd);
+    return launch_cost_grad_t<double, false>(s, a, kd);
 }
 
 template <typename T, int GROUP, int PPL, bool FAST>
-static int launch_optimize_t(hipStream_t s, const SolveArgs& a, const DevConst& k) {
+static int launch_optimize_t(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd) {
     const int tpb = kWave / GROUP;
     const size_t lds = optimize_lds_bytes<T, GROUP>(a.N, k.mem_size);
     if (lds > kLdsPerWorkgroup) return (int)hipErrorInvalidValue;  // refused earlier by vigo_optimize
@@ -1031,25 +1041,26 @@ static int launch_optimize_t(hipStream_t s, const SolveArgs& a, const DevConst& 
         attr_set = true;
     }
     dim3 grid((a.B + tpb - 1) / tpb), block(kWave);
-    hipLaunchKernelGGL((k_optimize<T, GROUP, PPL, FAST>), grid, block, lds, s, a, k);
+    hipLaunchKernelGGL((k_optimize<T, GROUP, PPL, FAST>), grid, block, lds, s, a, kd);
     return (int)hipGetLastError();
 }
 
 template <typename T, bool FAST>
-static int launch_optimize_p(hipStream_t s, const SolveArgs& a, const DevConst& k) {
+static int launch_optimize_p(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd) {
     switch (shape_for(a.N)) {
-        case 0: return launch_optimize_t<T, 32, 1, FAST>(s, a, k);
-        case 1: return launch_optimize_t<T, 64, 1, FAST>(s, a, k);
-        case 2: return launch_optimize_t<T, 64, 2, FAST>(s, a, k);
-        default: return launch_optimize_t<T, 64, 4, FAST>(s, a, k);
+        // (a 16-lane x 2-point shape saves one butterfly level but measured 22 % slower: 1.76 M vs 2.26 M/s)
+        case 0: return launch_optimize_t<T, 32, 1, FAST>(s, a, k, kd);
+        case 1: return launch_optimize_t<T, 64, 1, FAST>(s, a, k, kd);
+        case 2: return launch_optimize_t<T, 64, 2, FAST>(s, a, k, kd);
+        default: return launch_optimize_t<T, 64, 4, FAST>(s, a, k, kd);
     }
 }
 
-int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, int precision) {
+int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, int precision) {
     if (a.B <= 0) return hipSuccess;
-    if (precision == VIGO_PREC_F32) return launch_optimize_p<float, false>(s, a, k);
-    if (precision == VIGO_PREC_F64_FAST) return launch_optimize_p<double, true>(s, a, k);
-    return launch_optimize_p<double, false>(s, a, k);
+    if (precision == VIGO_PREC_F32) return launch_optimize_p<float, false>(s, a, k, kd);
+    if (precision == VIGO_PREC_F64_FAST) return launch_optimize_p<double, true>(s, a, k, kd);
+    return launch_optimize_p<double, false>(s, a, k, kd);
 }
 
 // bytes of LDS one trajectory-solve workgroup needs; the C ABI refuses N it cannot hold
