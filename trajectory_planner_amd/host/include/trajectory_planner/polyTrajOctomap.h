@@ -1,20 +1,19 @@
 /*
- * polyTrajOctomap.h — trajPlanner::polyTrajOctomap: the corridor-collision side of the
- * reference's min-snap planner (include/trajectory_planner/polyTrajOctomap.h:60-135) over the
- * MI355X back-end.
+ * polyTrajOctomap.h — trajPlanner::polyTrajOctomap with the reference's public interface
+ * (include/trajectory_planner/polyTrajOctomap.h:60-135) over the MI355X back-end.
  *
- * In scope: checkCollision / checkCollisionPoint / checkCollisionLine /
- * checkCollisionTraj (PO.cpp:547-656), the polynomial sampler getPose / getTrajectory
- * (PS.cpp:1026-1056, :1125-1137), getDuration, updatePath, updateInitVel/Acc.
- * NOT in this round: the min-snap QP itself (polyTrajSolver + OSQP, SURVEY.md §8f "next" #3) —
- * the piecewise polynomial is handed in with setSolution(); makePlan() then runs the reference's
- * corridor loop body on it (sample -> device box sweep -> colliding segments) and reports
- * whether the trajectory is valid.  The map comes from a dense mapManager::occMap stand-in
- * instead of the /octomap_binary service (PO.cpp:133-145).
+ * makePlan(): waypoint path -> min-snap QP (polyTrajSolver, host) -> sampled trajectory -> box-sweep
+ * collision check of every sample on the DEVICE (vigo_box_collision_points, the batched
+ * checkCollision of PO.cpp:547-589) -> shrink the colliding segments' corridors or insert
+ * waypoints -> repeat (PO.cpp:259-545); piecewise-linear fallback when no valid trajectory is found.
+ * Differences to the reference: the map arrives through setMap() (a dense mapManager::occMap, e.g.
+ * from loadOctomapBt) instead of the /octomap_binary service (PO.cpp:133-145); no RViz publisher
+ * threads; in the adding-waypoint mode the solver's path IS refreshed after insertWaypoint().
  */
 #ifndef POLYTRAJOCTOMAP_H
 #define POLYTRAJOCTOMAP_H
 #include <trajectory_planner/compat.h>
+#include <trajectory_planner/polyTrajSolver.h>
 #include <trajectory_planner/utils.h>
 
 #include <memory>
@@ -28,19 +27,30 @@ class polyTrajOctomap {
 private:
     ros::NodeHandle nh_;
     std::vector<double> collisionBox_;  // collision_box, PO.cpp:14-25
-    double mapRes_;                     // map_resolution
-    double delT_;                       // sample_delta_time
-    int polyDegree_;
+    double mapRes_, delT_, desiredVel_, timeout_, initR_, fs_, corridorRes_;
+    int polyDegree_, diffDegree_, continuityDegree_, maxIter_;
+    bool mode_;                         // true: adding waypoints, false: corridor constraint
     std::vector<pose> path_;
-    std::vector<double> xSol_, ySol_, zSol_;  // (polyDegree_+1) coefficients per segment, local time
-    std::vector<double> desiredTime_;         // time knots
+    std::unique_ptr<polyTrajSolver> trajSolver_;
+    // an externally supplied piecewise polynomial (setSolution) or the PWL fallback
+    int extDegree_ = 0;
+    std::vector<double> xSol_, ySol_, zSol_, extKnots_;
+    std::vector<double> pwlKnots_;
     bool findValidTraj_ = false;
-    geometry_msgs::Point initVel_, initAcc_;
+    double initVel_[3] = {0, 0, 0}, initAcc_[3] = {0, 0, 0};
     std::shared_ptr<mapManager::occMap> map_;
     vigo_context* dev_ = nullptr;
     uint64_t mapVersion_ = 0;
+    int lastIterations_ = 0;
     bool syncDevice();
     bool sweepPoints(const std::vector<pose>& pts, std::vector<uint8_t>& flags);
+    void insertWaypoint(const std::set<int>& seg);
+    void makePlanAddingWaypoint(std::vector<pose>& trajectory, double delT);
+    void makePlanCorridorConstraint(std::vector<pose>& trajectory, double delT);
+    void pwlPlan(std::vector<pose>& trajectory, double delT);
+    pose pwlPose(double t);
+    pose extPose(double t);
+    const std::vector<double>& timeKnots();
 
 public:
     polyTrajOctomap();
@@ -54,7 +64,8 @@ public:
     void updatePath(const std::vector<pose>& path);
     void updateInitVel(double vx, double vy, double vz);
     void updateInitAcc(double ax, double ay, double az);
-    /* the min-snap solution: coefficient blocks of (degree+1) per segment and axis, time knots */
+    void setDefaultInit();
+    /* bypass the QP with a given piecewise polynomial (coefficient blocks per segment, time knots) */
     void setSolution(int polyDegree, const std::vector<double>& xSol, const std::vector<double>& ySol,
                      const std::vector<double>& zSol, const std::vector<double>& timeKnot);
 
@@ -67,11 +78,11 @@ public:
     bool checkCollisionTraj(const std::vector<pose>& trajectory, std::vector<int>& collisionIdx);           // PO.cpp:619-632
     bool checkCollisionTraj(const std::vector<pose>& trajectory, double delT, std::set<int>& collisionSeg);  // PO.cpp:634-656
 
-    pose getPoseAt(double t);                                       // polyTrajSolver::getPose, PS.cpp:1026-1056
-    void getTrajectory(std::vector<pose>& trajectory, double delT);  // PS.cpp:1125-1137
     geometry_msgs::PoseStamped getPose(double t);                   // PO.cpp:658-677
     double getDuration();                                           // PO.cpp:679-689
     bool isValid() const { return findValidTraj_; }
+    int getIterations() const { return lastIterations_; }
+    const std::vector<pose>& getPath() const { return path_; }
     void trajMsgConverter(const std::vector<pose>& trajectoryTemp, nav_msgs::Path& trajectory);
 };
 }  // namespace trajPlanner

@@ -1,0 +1,67 @@
+/*
+ * polyTrajSolver.h — min-snap piecewise-polynomial QP with the reference's public interface
+ * (include/trajectory_planner/polyTrajSolver.h:25-147): per-axis QP in normalised segment time,
+ * continuity up to `continuityDegree`, optional corridor boxes; coefficients are rescaled to
+ * un-normalised local time after the solve (polyTrajSolver.cpp:874-878).
+ *
+ * The reference hands the three QPs to OSQP 0.6.2 through OsqpEigen (prebuilt third-party
+ * binaries, never loaded here).  This build solves them with its own dense ADMM of the same
+ * splitting (Stellato et al., "OSQP: an operator splitting solver for quadratic programs", 2020:
+ * sigma = 1e-6, alpha = 1.6, rho_eq = 1e3 rho), run to a tighter tolerance than OSQP's default
+ * 1e-3 — host-side plumbing for BASELINE config 1 (SURVEY.md §8f "next" #3), parity unpinned.
+ */
+#ifndef POLYTRAJSOLVER_H
+#define POLYTRAJSOLVER_H
+#include <trajectory_planner/compat.h>
+#include <trajectory_planner/utils.h>
+
+#include <vector>
+
+namespace trajPlanner {
+
+/* min 1/2 x'Px + q'x  s.t.  l <= Ax <= u  (dense, row-major); returns iterations or -1 */
+int solveDenseQP(int n, int m, const std::vector<double>& P, const std::vector<double>& q, const std::vector<double>& A,
+                 const std::vector<double>& l, const std::vector<double>& u, std::vector<double>& x, double eps = 1e-7,
+                 int maxIter = 20000);
+
+class polyTrajSolver {
+private:
+    int polyDegree_, diffDegree_, continuityDegree_;
+    int paramDim_ = 0, constraintNum_ = 0;
+    double desiredVel_;
+    std::vector<pose> path_;
+    std::vector<double> desiredTime_;
+    double initVel_[3] = {0, 0, 0}, endVel_[3] = {0, 0, 0}, initAcc_[3] = {0, 0, 0}, endAcc_[3] = {0, 0, 0};
+    std::vector<double> xSol_, ySol_, zSol_;
+    bool corridorConstraint_ = false;
+    double corridorRes_ = 5.0;
+    std::vector<double> corridorSizeVec_;
+    std::vector<std::vector<std::pair<double, pose>>> segToTimePose_;  // (normalised time, box centre) per segment
+    bool solved_ = false;
+
+    int getConstraintNum() const;
+    void avgTimeAllocation();
+    void updateCorridorParam();
+    void constructP(std::vector<double>& P) const;
+    void constructA(std::vector<double>& A) const;
+    void constructBound(std::vector<double> (&l)[3], std::vector<double> (&u)[3]) const;
+
+public:
+    polyTrajSolver(int polyDegree, int diffDegree, int continuityDegree, double desiredVel);
+    void updatePath(const std::vector<pose>& path);
+    void updateInitVel(double vx, double vy, double vz);
+    void updateEndVel(double vx, double vy, double vz);
+    void updateInitAcc(double ax, double ay, double az);
+    void updateEndAcc(double ax, double ay, double az);
+    void setCorridorConstraint(const std::vector<double>& corridorSizeVec, double corridorRes);
+    void setCorridorConstraint(double corridorSize, double corridorRes);
+    bool solve();   // the reference's solve() is void and silently keeps a stale solution on failure
+    pose getPose(double t);
+    void getTrajectory(std::vector<pose>& trajectory, double delT);
+    std::vector<double>& getTimeKnot();
+    const std::vector<double>& getSolution(int axis) const { return axis == 0 ? xSol_ : (axis == 1 ? ySol_ : zSol_); }
+    int getPolyDegree() const { return polyDegree_; }
+    void getCorridor(std::vector<std::vector<std::pair<double, pose>>>& segToTimePose, std::vector<double>& corridorSizeVec) const;
+};
+}  // namespace trajPlanner
+#endif

@@ -1,0 +1,51 @@
+// cabi_host.cpp — small extern "C" entry points of libtrajectory_planner_vigo.so so the Python
+// tests can exercise the host-side pieces that have no GPU part (the .bt reader and the min-snap
+// QP) with ctypes.  Not part of include/vigo.h (that is the device ABI).
+#include <trajectory_planner/octomapBt.h>
+#include <trajectory_planner/polyTrajSolver.h>
+
+#include <cstring>
+
+extern "C" {
+
+// returns 0 on success; info: nodes_header, nodes_parsed, bytes, occupied, free, nx, ny, nz; origin[3]; res
+int vigo_host_bt_info(const char* path, long long* info, double* origin, double* res) {
+    trajPlanner::BtInfo bi;
+    const double inflate[3] = {0, 0, 0};
+    auto m = trajPlanner::loadOctomapBt(path, inflate, 0, &bi);
+    if (!m) return -1;
+    info[0] = bi.nodes_header; info[1] = bi.nodes_parsed; info[2] = bi.bytes_consumed; info[3] = bi.occupied; info[4] = bi.free_;
+    info[5] = m->nx(); info[6] = m->ny(); info[7] = m->nz();
+    for (int a = 0; a < 3; ++a) origin[a] = m->origin()(a);
+    *res = m->getRes();
+    return 0;
+}
+
+// dense voxels of a .bt (caller allocates nx*ny*nz bytes as reported by vigo_host_bt_info with the same arguments)
+int vigo_host_bt_load(const char* path, const double* inflate, int margin, unsigned char* out, long long cap, int* dims, double* origin) {
+    auto m = trajPlanner::loadOctomapBt(path, inflate, margin, nullptr);
+    if (!m) return -1;
+    dims[0] = m->nx(); dims[1] = m->ny(); dims[2] = m->nz();
+    for (int a = 0; a < 3; ++a) origin[a] = m->origin()(a);
+    if ((long long)m->voxels().size() > cap) return -2;
+    std::memcpy(out, m->voxels().data(), m->voxels().size());
+    return 0;
+}
+
+// min-snap through n_wp waypoints (xyz triples); corridor == NULL: equality-constrained only.
+// coeffs_out: 3 * (n_wp-1) * (deg+1) doubles (x block, y block, z block), knots_out: n_wp doubles.
+int vigo_host_minsnap(int n_wp, const double* wp, int deg, int diff, int cont, double vel, const double* corridor,
+                      double corridor_res, double* coeffs_out, double* knots_out) {
+    std::vector<trajPlanner::pose> path;
+    for (int i = 0; i < n_wp; ++i) path.push_back(trajPlanner::pose(wp[3 * i], wp[3 * i + 1], wp[3 * i + 2]));
+    trajPlanner::polyTrajSolver s(deg, diff, cont, vel);
+    s.updatePath(path);
+    if (corridor) s.setCorridorConstraint(std::vector<double>(corridor, corridor + n_wp - 1), corridor_res);
+    if (!s.solve()) return -1;
+    const int n = (n_wp - 1) * (deg + 1);
+    for (int a = 0; a < 3; ++a) std::memcpy(coeffs_out + (size_t)a * n, s.getSolution(a).data(), sizeof(double) * n);
+    std::memcpy(knots_out, s.getTimeKnot().data(), sizeof(double) * n_wp);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+// octomapBt.cpp — .bt reader (see the header for the format).  Two passes over the byte stream:
+// bounds, then fill.  Own implementation of the published octomap binary format.
+#include <trajectory_planner/octomapBt.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <vector>
+
+namespace trajPlanner {
+namespace {
+
+struct Walker {
+    const unsigned char* p;
+    const unsigned char* end;
+    long long nodes = 0;
+    bool ok = true;
+    // pass 1: bounds; pass 2: fill
+    int kmin[3] = {1 << 30, 1 << 30, 1 << 30}, kmax[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
+    long long occ = 0, fre = 0;
+    mapManager::occMap* map = nullptr;
+    int o[3] = {0, 0, 0};  // key of map voxel (0,0,0)
+
+    void leaf(int x0, int y0, int z0, int size, bool occupied) {
+        if (occupied) occ += (long long)size * size * size; else fre += (long long)size * size * size;
+        const int lo[3] = {x0, y0, z0};
+        for (int a = 0; a < 3; ++a) {
+            kmin[a] = std::min(kmin[a], lo[a]);
+            kmax[a] = std::max(kmax[a], lo[a] + size - 1);
+        }
+        if (!map) return;
+        for (int x = x0; x < x0 + size; ++x)
+            for (int y = y0; y < y0 + size; ++y)
+                for (int z = z0; z < z0 + size; ++z) {
+                    const int ix = x - o[0], iy = y - o[1], iz = z - o[2];
+                    if (ix < 0 || iy < 0 || iz < 0 || ix >= map->nx() || iy >= map->ny() || iz >= map->nz()) continue;
+                    uint8_t& v = map->at(ix, iy, iz);
+                    v = (uint8_t)((v & ~2u) | (occupied ? 4u : 0u));  // observed; occupied or free
+                }
+    }
+
+    // one inner node: 2 bytes, then its inner children in index order (pre-order)
+    void inner(int x0, int y0, int z0, int size, int depth) {
+        if (!ok) return;
+        if (end - p < 2 || depth >= 16) { ok = false; return; }
+        const unsigned bits = (unsigned)p[0] | ((unsigned)p[1] << 8);
+        p += 2;
+        ++nodes;
+        const int h = size / 2;
+        unsigned kind[8];
+        for (int i = 0; i < 8; ++i) kind[i] = (bits >> (2 * i)) & 3u;  // bit0 | bit1 << 1
+        for (int i = 0; i < 8; ++i) {
+            const int cx = x0 + ((i & 1) ? h : 0), cy = y0 + ((i & 2) ? h : 0), cz = z0 + ((i & 4) ? h : 0);
+            if (kind[i] == 1u) { ++nodes; leaf(cx, cy, cz, h, false); }       // bit0=1, bit1=0: free
+            else if (kind[i] == 2u) { ++nodes; leaf(cx, cy, cz, h, true); }   // bit0=0, bit1=1: occupied
+        }
+        for (int i = 0; i < 8; ++i) {
+            if (kind[i] != 3u) continue;
+            const int cx = x0 + ((i & 1) ? h : 0), cy = y0 + ((i & 2) ? h : 0), cz = z0 + ((i & 4) ? h : 0);
+            inner(cx, cy, cz, h, depth + 1);
+        }
+    }
+};
+
+}  // namespace
+
+std::shared_ptr<mapManager::occMap> loadOctomapBt(const std::string& path, const double inflate[3], int margin, BtInfo* info) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return nullptr;
+    std::vector<unsigned char> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    // header
+    size_t pos = 0;
+    long long size = -1;
+    double res = 0.0;
+    bool data = false;
+    while (pos < buf.size()) {
+        size_t e = pos;
+        while (e < buf.size() && buf[e] != '\n') ++e;
+        std::string line(buf.begin() + pos, buf.begin() + e);
+        pos = e + 1;
+        if (line.rfind("size", 0) == 0) size = std::atoll(line.c_str() + 4);
+        else if (line.rfind("res", 0) == 0) res = std::atof(line.c_str() + 3);
+        else if (line.rfind("data", 0) == 0) { data = true; break; }
+    }
+    if (!data || size < 0 || !(res > 0)) return nullptr;
+
+    Walker w1;
+    w1.p = buf.data() + pos;
+    w1.end = buf.data() + buf.size();
+    if (size > 0) w1.inner(-32768, -32768, -32768, 65536, 0);   // keys relative to 32768
+    if (!w1.ok) return nullptr;
+    const long long parsed = w1.nodes;  // inner nodes (root included) + leaves
+    BtInfo bi;
+    bi.nodes_header = size;
+    bi.nodes_parsed = parsed;
+    bi.bytes_consumed = (long long)(w1.p - (buf.data() + pos));
+    bi.res = res;
+    bi.occupied = w1.occ;
+    bi.free_ = w1.fre;
+    if (w1.kmax[0] < w1.kmin[0]) { if (info) *info = bi; return nullptr; }
+    for (int a = 0; a < 3; ++a) { bi.key_min[a] = w1.kmin[a]; bi.key_max[a] = w1.kmax[a]; }
+    if (info) *info = bi;
+
+    int n[3], o[3];
+    for (int a = 0; a < 3; ++a) {
+        o[a] = w1.kmin[a] - margin;
+        n[a] = w1.kmax[a] - w1.kmin[a] + 1 + 2 * margin;
+    }
+    auto map = std::make_shared<mapManager::occMap>(n[0], n[1], n[2], Eigen::Vector3d(o[0] * res, o[1] * res, o[2] * res), res);
+    std::fill(map->voxels().begin(), map->voxels().end(), (uint8_t)2);  // everything unknown until observed
+    Walker w2;
+    w2.p = buf.data() + pos;
+    w2.end = buf.data() + buf.size();
+    w2.map = map.get();
+    for (int a = 0; a < 3; ++a) w2.o[a] = o[a];
+    w2.inner(-32768, -32768, -32768, 65536, 0);
+    // inflation of the occupied voxels (bit0), separable box dilation
+    const int r[3] = {(int)std::ceil(inflate[0] / res - 1e-9), (int)std::ceil(inflate[1] / res - 1e-9), (int)std::ceil(inflate[2] / res - 1e-9)};
+    std::vector<uint8_t> cur((size_t)n[0] * n[1] * n[2]), nxt(cur.size());
+    for (size_t i = 0; i < cur.size(); ++i) cur[i] = (map->voxels()[i] & 4u) ? 1 : 0;
+    auto idx = [&](int x, int y, int z) { return ((size_t)x * n[1] + y) * n[2] + z; };
+    for (int axis = 0; axis < 3; ++axis) {
+        std::fill(nxt.begin(), nxt.end(), 0);
+        for (int x = 0; x < n[0]; ++x) for (int y = 0; y < n[1]; ++y) for (int z = 0; z < n[2]; ++z) {
+            if (!cur[idx(x, y, z)]) continue;
+            for (int d = -r[axis]; d <= r[axis]; ++d) {
+                int q[3] = {x, y, z};
+                q[axis] += d;
+                if (q[axis] < 0 || q[axis] >= n[axis]) continue;
+                nxt[idx(q[0], q[1], q[2])] = 1;
+            }
+        }
+        cur.swap(nxt);
+    }
+    for (size_t i = 0; i < cur.size(); ++i) if (cur[i]) map->voxels()[i] |= 1u;
+    ++map->version;
+    return map;
+}
+
+}  // namespace trajPlanner

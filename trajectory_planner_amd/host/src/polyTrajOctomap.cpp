@@ -1,10 +1,11 @@
-// polyTrajOctomap.cpp — corridor-collision facade (see the header for scope).  Behaviour follows
-// polyTrajOctomap.cpp:547-689 and polyTrajSolver.cpp:1026-1137; the box sweep runs on the device
-// (vigo_box_collision_points, include/vigo.h).
+// polyTrajOctomap.cpp — min-snap + corridor planner facade (see the header).  Behaviour follows
+// polyTrajOctomap.cpp:14-110 (parameters), :178-192, :226-545 (planning loops), :547-689 (checker,
+// getters); the box sweep of every trajectory sample runs on the device.
 #include <trajectory_planner/polyTrajOctomap.h>
 
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <cmath>
 #include <iostream>
 
@@ -15,14 +16,25 @@ using std::endl;
 
 namespace trajPlanner {
 
+static double nowSec() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 polyTrajOctomap::polyTrajOctomap() : polyTrajOctomap(ros::NodeHandle()) {}
 
 polyTrajOctomap::polyTrajOctomap(const ros::NodeHandle& nh) : nh_(nh) {
-    // PO.cpp:14-25, :45-60 keys (un-namespaced, as in the reference)
+    // PO.cpp:14-108: same (un-namespaced) keys and fall-back values
     if (!nh_.getParam("collision_box", collisionBox_) || collisionBox_.size() < 3) collisionBox_ = {0.5, 0.5, 0.5};
-    if (!nh_.getParam("map_resolution", mapRes_)) mapRes_ = 0.2;
-    if (!nh_.getParam("sample_delta_time", delT_)) delT_ = 0.1;
     if (!nh_.getParam("polynomial_degree", polyDegree_)) polyDegree_ = 7;
+    if (!nh_.getParam("differential_degree", diffDegree_)) diffDegree_ = 4;
+    if (!nh_.getParam("continuity_degree", continuityDegree_)) continuityDegree_ = 4;
+    if (!nh_.getParam("desired_velocity", desiredVel_)) desiredVel_ = 1.0;
+    if (!nh_.getParam("map_resolution", mapRes_)) mapRes_ = 0.2;
+    if (!nh_.getParam("maximum_iteration_num", maxIter_)) maxIter_ = 20;
+    if (!nh_.getParam("traj_timeout", timeout_)) timeout_ = 0.1;
+    if (!nh_.getParam("mode", mode_)) mode_ = true;
+    if (!nh_.getParam("sample_delta_time", delT_)) delT_ = 0.1;
+    if (!nh_.getParam("initial_radius", initR_)) initR_ = 0.5;
+    if (!nh_.getParam("shrinking_factor", fs_)) fs_ = 0.8;
+    if (!nh_.getParam("corridor_res", corridorRes_)) corridorRes_ = 5.0;
 }
 
 polyTrajOctomap::~polyTrajOctomap() {
@@ -55,51 +67,33 @@ void polyTrajOctomap::updatePath(const nav_msgs::Path& path) {
     this->updatePath(trajPath);
 }
 
-void polyTrajOctomap::updatePath(const std::vector<pose>& path) { this->path_ = path; }
-void polyTrajOctomap::updateInitVel(double vx, double vy, double vz) { initVel_.x = vx; initVel_.y = vy; initVel_.z = vz; }
-void polyTrajOctomap::updateInitAcc(double ax, double ay, double az) { initAcc_.x = ax; initAcc_.y = ay; initAcc_.z = az; }
+void polyTrajOctomap::updatePath(const std::vector<pose>& path) { this->path_ = path; extKnots_.clear(); }
+void polyTrajOctomap::updateInitVel(double vx, double vy, double vz) { initVel_[0] = vx; initVel_[1] = vy; initVel_[2] = vz; }
+void polyTrajOctomap::updateInitAcc(double ax, double ay, double az) { initAcc_[0] = ax; initAcc_[1] = ay; initAcc_[2] = az; }
+void polyTrajOctomap::setDefaultInit() { updateInitVel(0, 0, 0); updateInitAcc(0, 0, 0); }
 
 void polyTrajOctomap::setSolution(int polyDegree, const std::vector<double>& xSol, const std::vector<double>& ySol,
                                   const std::vector<double>& zSol, const std::vector<double>& timeKnot) {
-    polyDegree_ = polyDegree;
+    extDegree_ = polyDegree;
     xSol_ = xSol; ySol_ = ySol; zSol_ = zSol;
-    desiredTime_ = timeKnot;
+    extKnots_ = timeKnot;
+    trajSolver_.reset();
 }
 
-// PS.cpp:1026-1056 (including the t == 0 -> 0.01 nudge of the yaw derivative)
-pose polyTrajOctomap::getPoseAt(double t) {
-    pose p;
-    for (size_t i = 0; i + 1 < desiredTime_.size(); ++i) {
-        const double startTime = desiredTime_[i], endTime = desiredTime_[i + 1];
-        if (t >= startTime && t <= endTime) {
-            t = (double)(t - startTime);
-            const int c0 = (polyDegree_ + 1) * (int)i;
-            double x = 0, y = 0, z = 0;
-            for (int d = 0; d < polyDegree_ + 1; ++d) {
-                x += xSol_[c0 + d] * std::pow(t, d);
-                y += ySol_[c0 + d] * std::pow(t, d);
-                z += zSol_[c0 + d] * std::pow(t, d);
-            }
-            if (t == 0) t = 0.01;
-            double dx = 0, dy = 0;
-            for (int d = 0; d < polyDegree_ + 1; ++d) {
-                dx += d * xSol_[c0 + d] * std::pow(t, d - 1);
-                dy += d * ySol_[c0 + d] * std::pow(t, d - 1);
-            }
-            p.x = x; p.y = y; p.z = z; p.yaw = std::atan2(dy, dx);
-            break;
-        }
+// PO.cpp:178-186
+void polyTrajOctomap::insertWaypoint(const std::set<int>& seg) {
+    for (auto rit = seg.rbegin(); rit != seg.rend(); ++rit) {
+        const int idx = *rit;
+        if (idx < 0 || idx + 1 >= (int)path_.size()) continue;
+        const pose p1 = path_[idx], p2 = path_[idx + 1];
+        path_.insert(path_.begin() + idx + 1, pose((p1.x + p2.x) / 2, (p1.y + p2.y) / 2, (p1.z + p2.z) / 2));
     }
-    return p;
 }
 
-// PS.cpp:1125-1137
-void polyTrajOctomap::getTrajectory(std::vector<pose>& trajectory, double delT) {
-    trajectory.clear();
-    if (desiredTime_.empty()) return;
-    const double endTime = desiredTime_.back();
-    for (double t = 0; t < endTime; t += delT) trajectory.push_back(this->getPoseAt(t));
-    if (!path_.empty()) trajectory.push_back(path_.back());
+const std::vector<double>& polyTrajOctomap::timeKnots() {
+    if (trajSolver_) return trajSolver_->getTimeKnot();
+    if (!extKnots_.empty()) return extKnots_;
+    return pwlKnots_;
 }
 
 bool polyTrajOctomap::sweepPoints(const std::vector<pose>& pts, std::vector<uint8_t>& flags) {
@@ -153,38 +147,152 @@ bool polyTrajOctomap::checkCollisionTraj(const std::vector<pose>& trajectory, st
     return has;
 }
 
-// PO.cpp:634-656: t accumulates delT per sample; first time knot interval containing t (inclusive)
+// PO.cpp:634-656: t accumulates delT per sample; first time-knot interval containing t (inclusive)
 bool polyTrajOctomap::checkCollisionTraj(const std::vector<pose>& trajectory, double delT, std::set<int>& collisionSeg) {
     collisionSeg.clear();
     std::vector<uint8_t> f;
     sweepPoints(trajectory, f);
+    const std::vector<double>& knots = timeKnots();
     double t = 0;
     bool has = false;
     for (size_t k = 0; k < trajectory.size(); ++k) {
         if (f[k]) {
             has = true;
-            for (size_t i = 0; i + 1 < desiredTime_.size(); ++i) {
-                if (t >= desiredTime_[i] && t <= desiredTime_[i + 1]) { collisionSeg.insert((int)i); break; }
-            }
+            for (size_t i = 0; i + 1 < knots.size(); ++i)
+                if (t >= knots[i] && t <= knots[i + 1]) { collisionSeg.insert((int)i); break; }
         }
         t += delT;
     }
     return has;
 }
 
-// One pass of the corridor loop body (PO.cpp:430-432 / :513-515) on the installed solution.
+// ---- piecewise-linear fallback (role of pwlTraj, piecewiseLinearTraj.cpp:83-121, :163-197): constant
+// speed along the path, yaw along each leg ----
+void polyTrajOctomap::pwlPlan(std::vector<pose>& trajectory, double delT) {
+    pwlKnots_.assign(1, 0.0);
+    for (size_t i = 1; i < path_.size(); ++i) {
+        const double d = std::sqrt(std::pow(path_[i].x - path_[i - 1].x, 2) + std::pow(path_[i].y - path_[i - 1].y, 2) +
+                                   std::pow(path_[i].z - path_[i - 1].z, 2));
+        pwlKnots_.push_back(pwlKnots_.back() + d / desiredVel_);
+    }
+    trajectory.clear();
+    for (double t = 0; t < pwlKnots_.back(); t += delT) trajectory.push_back(pwlPose(t));
+    trajectory.push_back(path_.back());
+}
+
+pose polyTrajOctomap::pwlPose(double t) {
+    for (size_t i = 0; i + 1 < pwlKnots_.size(); ++i) {
+        if (t >= pwlKnots_[i] && t <= pwlKnots_[i + 1]) {
+            const double a = pwlKnots_[i + 1] > pwlKnots_[i] ? (t - pwlKnots_[i]) / (pwlKnots_[i + 1] - pwlKnots_[i]) : 0.0;
+            const pose &p = path_[i], &q = path_[i + 1];
+            return pose(p.x + (q.x - p.x) * a, p.y + (q.y - p.y) * a, p.z + (q.z - p.z) * a, std::atan2(q.y - p.y, q.x - p.x));
+        }
+    }
+    return path_.empty() ? pose() : path_.back();
+}
+
+// polyTrajSolver::getPose on an externally supplied polynomial (PS.cpp:1026-1056)
+pose polyTrajOctomap::extPose(double t) {
+    pose p;
+    for (size_t i = 0; i + 1 < extKnots_.size(); ++i) {
+        if (t >= extKnots_[i] && t <= extKnots_[i + 1]) {
+            t = (double)(t - extKnots_[i]);
+            const int c0 = (extDegree_ + 1) * (int)i;
+            double x = 0, y = 0, z = 0;
+            for (int d = 0; d < extDegree_ + 1; ++d) {
+                x += xSol_[c0 + d] * std::pow(t, d);
+                y += ySol_[c0 + d] * std::pow(t, d);
+                z += zSol_[c0 + d] * std::pow(t, d);
+            }
+            if (t == 0) t = 0.01;
+            double dx = 0, dy = 0;
+            for (int d = 0; d < extDegree_ + 1; ++d) {
+                dx += d * xSol_[c0 + d] * std::pow(t, d - 1);
+                dy += d * ySol_[c0 + d] * std::pow(t, d - 1);
+            }
+            p.x = x; p.y = y; p.z = z; p.yaw = std::atan2(dy, dx);
+            break;
+        }
+    }
+    return p;
+}
+
+// PO.cpp:472-545
+void polyTrajOctomap::makePlanCorridorConstraint(std::vector<pose>& trajectory, double delT) {
+    this->setDefaultInit();
+    trajSolver_.reset(new polyTrajSolver(polyDegree_, diffDegree_, continuityDegree_, desiredVel_));
+    trajSolver_->updatePath(path_);
+    trajSolver_->updateInitVel(initVel_[0], initVel_[1], initVel_[2]);
+    trajSolver_->updateInitAcc(initAcc_[0], initAcc_[1], initAcc_[2]);
+    std::vector<double> corridorSizeVec(path_.size() - 1, initR_);
+    int countIter = 0;
+    bool valid = false;
+    const double t0 = nowSec();
+    while (!valid) {
+        if (nowSec() - t0 >= timeout_) { cout << "[Trajectory Planner INFO]: Timeout." << endl; break; }
+        trajSolver_->setCorridorConstraint(corridorSizeVec, corridorRes_);
+        trajSolver_->solve();
+        trajSolver_->getTrajectory(trajectory, delT);
+        std::set<int> collisionSeg;
+        valid = !this->checkCollisionTraj(trajectory, delT, collisionSeg);
+        if (!valid)
+            for (int s : collisionSeg) corridorSizeVec[s] *= fs_;   // adjustCorridorSize, PO.cpp:188-192
+        ++countIter;
+        if (countIter > maxIter_) break;
+    }
+    lastIterations_ = countIter;
+    findValidTraj_ = valid;
+}
+
+// PO.cpp:259-386
+void polyTrajOctomap::makePlanAddingWaypoint(std::vector<pose>& trajectory, double delT) {
+    this->setDefaultInit();
+    trajSolver_.reset(new polyTrajSolver(polyDegree_, diffDegree_, continuityDegree_, desiredVel_));
+    trajSolver_->updateInitVel(initVel_[0], initVel_[1], initVel_[2]);
+    trajSolver_->updateInitAcc(initAcc_[0], initAcc_[1], initAcc_[2]);
+    trajSolver_->updatePath(path_);
+    int countIter = 0;
+    bool valid = false;
+    const double t0 = nowSec();
+    while (!valid) {
+        if (nowSec() - t0 >= timeout_) { cout << "[Trajectory Planner INFO]: Timeout." << endl; break; }
+        trajSolver_->solve();
+        trajSolver_->getTrajectory(trajectory, delT);
+        std::set<int> collisionSeg;
+        valid = !this->checkCollisionTraj(trajectory, delT, collisionSeg);
+        if (!valid) {
+            this->insertWaypoint(collisionSeg);
+            trajSolver_->updatePath(path_);   // (the reference never refreshes the solver's path here)
+        }
+        ++countIter;
+        if (countIter > maxIter_) break;
+    }
+    lastIterations_ = countIter;
+    findValidTraj_ = valid;
+}
+
 void polyTrajOctomap::makePlan(std::vector<pose>& trajectory, double delT) {
     this->findValidTraj_ = false;
+    if (this->path_.empty()) return;
     if (this->path_.size() == 1) { trajectory = this->path_; this->findValidTraj_ = true; return; }
-    if (desiredTime_.size() < 2) {
-        cout << "[Trajectory Planner INFO]: no min-snap solution installed (the QP is outside this round's scope)." << endl;
+    if (!extKnots_.empty() && !trajSolver_) {
+        // an installed polynomial: one pass of the loop body (sample -> device sweep)
+        trajectory.clear();
+        for (double t = 0; t < extKnots_.back(); t += delT) trajectory.push_back(extPose(t));
+        trajectory.push_back(path_.back());
+        std::set<int> collisionSeg;
+        findValidTraj_ = !this->checkCollisionTraj(trajectory, delT, collisionSeg);
         return;
     }
-    this->getTrajectory(trajectory, delT);
-    std::set<int> collisionSeg;
-    this->findValidTraj_ = !this->checkCollisionTraj(trajectory, delT, collisionSeg);
-    if (this->findValidTraj_) cout << "[Trajectory Planner INFO]: Found valid trajectory!" << endl;
-    else cout << "[Trajectory Planner INFO]: " << collisionSeg.size() << " colliding segment(s)." << endl;
+    if (mode_) makePlanAddingWaypoint(trajectory, delT);
+    else makePlanCorridorConstraint(trajectory, delT);
+    if (findValidTraj_) {
+        cout << "[Trajectory Planner INFO]: Found valid trajectory!" << endl;
+    } else {
+        cout << "[Trajectory Planner INFO]: Not found. Return the best. Please consider piecewise linear trajectory!!" << endl;
+        trajSolver_.reset();
+        pwlPlan(trajectory, delT);
+    }
 }
 
 void polyTrajOctomap::makePlan() {
@@ -213,17 +321,19 @@ void polyTrajOctomap::trajMsgConverter(const std::vector<pose>& trajectoryTemp, 
 // PO.cpp:658-677
 geometry_msgs::PoseStamped polyTrajOctomap::getPose(double t) {
     if (t > this->getDuration()) t = this->getDuration();
+    pose p = trajSolver_ ? trajSolver_->getPose(t) : (!extKnots_.empty() ? extPose(t) : pwlPose(t));
     geometry_msgs::PoseStamped ps;
-    pose p = this->getPoseAt(t);
     ps.pose.position.x = p.x; ps.pose.position.y = p.y; ps.pose.position.z = p.z;
     ps.pose.orientation = quaternion_from_rpy(0, 0, p.yaw);
     ps.header.frame_id = "map";
     return ps;
 }
 
+// PO.cpp:679-689
 double polyTrajOctomap::getDuration() {
-    if (this->path_.size() == 1 || desiredTime_.empty()) return 0.0;
-    return desiredTime_.back();
+    if (this->path_.size() == 1) return 0.0;
+    const std::vector<double>& k = timeKnots();
+    return k.empty() ? 0.0 : k.back();
 }
 
 }  // namespace trajPlanner
