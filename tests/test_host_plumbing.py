@@ -139,6 +139,27 @@ def test_bt_reader_on_the_reference_maps(host):
             assert (info[5], info[6], info[7]) == (219, 205, 41)
 
 
+def test_maze_fixture_is_the_parsed_reference_tree(host):
+    """tests/golden/maze_config1.npz (BASELINE configs[0] data) against SURVEY.md §8c and, in the
+    authoring container, against a fresh parse of the reference's map/maze.bt"""
+    f = np.load(os.path.join(ROOT, "tests", "golden", "maze_config1.npz"))
+    assert tuple(f["dims"]) == (219, 205, 41) and int(f["nodes"][0]) == 341148
+    assert float(f["res"][0]) == pytest.approx(0.1) and f["waypoints"].shape == (8, 3)
+    n = 219 * 205 * 41
+    occ = np.unpackbits(f["occ_bits"])[:n]
+    unk = np.unpackbits(f["unk_bits"])[:n]
+    assert occ.sum() == int(f["occupied"][0]) and not (occ & unk).any()
+    path = "/root/reference/map/maze.bt"
+    if os.path.exists(path):
+        dims = (C.c_int * 3)()
+        origin = (C.c_double * 3)()
+        inflate = (C.c_double * 3)(0, 0, 0)
+        buf = np.zeros(n + 4096, dtype=np.uint8)
+        assert host.vigo_host_bt_load(path.encode(), inflate, 0, buf.ctypes.data_as(C.c_void_p), buf.size, dims, origin) == 0
+        assert np.array_equal((buf[:n] & 4) != 0, occ.astype(bool)) and np.array_equal((buf[:n] & 2) != 0, unk.astype(bool))
+        assert np.allclose([origin[0], origin[1], origin[2]], f["origin"])
+
+
 # ---- min-snap QP
 def minsnap_matrices(wp, deg, diff, cont, vel):
     """numpy statement of the QP (normalised time) for the equality-constrained case"""

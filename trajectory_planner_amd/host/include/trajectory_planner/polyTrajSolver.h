@@ -5,10 +5,12 @@
  * un-normalised local time after the solve (polyTrajSolver.cpp:874-878).
  *
  * The reference hands the three QPs to OSQP 0.6.2 through OsqpEigen (prebuilt third-party
- * binaries, never loaded here).  This build solves them with its own dense ADMM of the same
- * splitting (Stellato et al., "OSQP: an operator splitting solver for quadratic programs", 2020:
- * sigma = 1e-6, alpha = 1.6, rho_eq = 1e3 rho), run to a tighter tolerance than OSQP's default
- * 1e-3 — host-side plumbing for BASELINE config 1 (SURVEY.md §8f "next" #3), parity unpinned.
+ * binaries, never loaded here; ADMM stopped at eps 1e-3).  This build solves them exactly: the
+ * equality rows (waypoints, continuity, end conditions: 6 per segment) are eliminated with an
+ * orthonormal null-space basis, leaving 2 free coefficients per segment, and the corridor boxes
+ * are handled by a Goldfarb-Idnani dual active-set iteration on that small strictly convex QP;
+ * an infeasible corridor is detected and reported.  Host-side plumbing for BASELINE config 1
+ * (SURVEY.md §8f "next" #3); parity vs OSQP is 1e-3-class by OSQP's own tolerance.
  */
 #ifndef POLYTRAJSOLVER_H
 #define POLYTRAJSOLVER_H
@@ -19,10 +21,10 @@
 
 namespace trajPlanner {
 
-/* min 1/2 x'Px + q'x  s.t.  l <= Ax <= u  (dense, row-major); returns iterations or -1 */
+/* min 1/2 x'Px + q'x  s.t.  l <= Ax <= u  (dense, row-major; P positive definite on the null space
+ * of the equality rows); returns active-set iterations >= 0, -1 numerical failure, -2 infeasible */
 int solveDenseQP(int n, int m, const std::vector<double>& P, const std::vector<double>& q, const std::vector<double>& A,
-                 const std::vector<double>& l, const std::vector<double>& u, std::vector<double>& x, double eps = 1e-7,
-                 int maxIter = 20000);
+                 const std::vector<double>& l, const std::vector<double>& u, std::vector<double>& x);
 
 class polyTrajSolver {
 private:

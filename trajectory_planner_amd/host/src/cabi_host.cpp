@@ -2,8 +2,10 @@
 // tests can exercise the host-side pieces that have no GPU part (the .bt reader and the min-snap
 // QP) with ctypes.  Not part of include/vigo.h (that is the device ABI).
 #include <trajectory_planner/octomapBt.h>
+#include <trajectory_planner/polyTrajOctomap.h>
 #include <trajectory_planner/polyTrajSolver.h>
 
+#include <chrono>
 #include <cstring>
 
 extern "C" {
@@ -45,6 +47,48 @@ int vigo_host_minsnap(int n_wp, const double* wp, int deg, int diff, int cont, d
     const int n = (n_wp - 1) * (deg + 1);
     for (int a = 0; a < 3; ++a) std::memcpy(coeffs_out + (size_t)a * n, s.getSolution(a).data(), sizeof(double) * n);
     std::memcpy(knots_out, s.getTimeKnot().data(), sizeof(double) * n_wp);
+    return 0;
+}
+
+// BASELINE configs[0]: one polyTrajOctomap::makePlan() (cfg/planner_interactive.yaml values passed in
+// `cfg`: box[3], map_resolution, sample_delta_time, desired_velocity, initial_radius, shrinking_factor,
+// corridor_res, maximum_iteration_num, traj_timeout, mode) on a dense byte grid (vigo.h voxel
+// contract).  traj_out: up to traj_cap xyz triples.  info_out: valid, iterations, samples, duration,
+// seconds of makePlan.  Needs the GPU (the box sweep of every sample runs there); -1 on failure.
+int vigo_host_poly_plan(int nx, int ny, int nz, const double* origin, double res, const unsigned char* voxels, int n_wp,
+                        const double* wp, const double* cfg, double* traj_out, int traj_cap, double* info_out) {
+    auto map = std::make_shared<mapManager::occMap>(nx, ny, nz, Eigen::Vector3d(origin[0], origin[1], origin[2]), res);
+    std::memcpy(map->voxels().data(), voxels, (size_t)nx * ny * nz);
+    ros::NodeHandle nh;
+    nh.setParam("collision_box", std::vector<double>{cfg[0], cfg[1], cfg[2]});
+    nh.setParam("map_resolution", cfg[3]);
+    nh.setParam("sample_delta_time", cfg[4]);
+    nh.setParam("desired_velocity", cfg[5]);
+    nh.setParam("initial_radius", cfg[6]);
+    nh.setParam("shrinking_factor", cfg[7]);
+    nh.setParam("corridor_res", cfg[8]);
+    nh.setParam("maximum_iteration_num", cfg[9]);
+    nh.setParam("traj_timeout", cfg[10]);
+    nh.setParam("mode", cfg[11]);
+    nh.setParam("polynomial_degree", 7.0);
+    nh.setParam("differential_degree", 4.0);
+    nh.setParam("continuity_degree", 4.0);
+    trajPlanner::polyTrajOctomap planner(nh);
+    planner.setMap(map);
+    std::vector<trajPlanner::pose> path, traj;
+    for (int i = 0; i < n_wp; ++i) path.push_back(trajPlanner::pose(wp[3 * i], wp[3 * i + 1], wp[3 * i + 2]));
+    if (planner.checkCollision(path.front())) { /* first device call: creates the handle, snapshots the map */ }
+    planner.updatePath(path);
+    const auto t0 = std::chrono::steady_clock::now();
+    planner.makePlan(traj, cfg[4]);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const int n = (int)traj.size() < traj_cap ? (int)traj.size() : traj_cap;
+    for (int i = 0; i < n; ++i) { traj_out[3 * i] = traj[i].x; traj_out[3 * i + 1] = traj[i].y; traj_out[3 * i + 2] = traj[i].z; }
+    info_out[0] = planner.isValid() ? 1.0 : 0.0;
+    info_out[1] = planner.getIterations();
+    info_out[2] = (double)traj.size();
+    info_out[3] = planner.getDuration();
+    info_out[4] = secs;
     return 0;
 }
 

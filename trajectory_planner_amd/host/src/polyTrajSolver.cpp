@@ -1,6 +1,7 @@
 // polyTrajSolver.cpp — min-snap QP (structure of polyTrajSolver.cpp:125-138, :156-160, :241-307,
-// :314-584, :587-846, :874-878, :985-1012, :1026-1056, :1125-1137 of the reference) and a small
-// dense ADMM QP solver.  Own implementation.
+// :314-584, :587-846, :874-878, :985-1012, :1026-1056, :1125-1137 of the reference) and an exact
+// dense QP solver (null-space elimination of the equalities + Goldfarb-Idnani dual active set)
+// in place of the reference's OSQP.  Own implementation.
 #include <trajectory_planner/polyTrajSolver.h>
 
 #include <algorithm>
@@ -9,7 +10,7 @@
 
 namespace trajPlanner {
 
-// ---- dense Cholesky helpers -------------------------------------------------------------
+// ---- small dense helpers (row-major) ------------------------------------------------------
 static bool cholesky(std::vector<double>& M, int n) {  // in place, lower
     for (int j = 0; j < n; ++j) {
         double d = M[(size_t)j * n + j];
@@ -25,7 +26,7 @@ static bool cholesky(std::vector<double>& M, int n) {  // in place, lower
     }
     return true;
 }
-static void cholSolve(const std::vector<double>& L, int n, std::vector<double>& b) {
+static void cholSolve(const std::vector<double>& L, int n, double* b) {
     for (int i = 0; i < n; ++i) {
         double s = b[i];
         for (int k = 0; k < i; ++k) s -= L[(size_t)i * n + k] * b[k];
@@ -38,103 +39,241 @@ static void cholSolve(const std::vector<double>& L, int n, std::vector<double>& 
     }
 }
 
-// ADMM of OSQP (Stellato et al. 2020, Algorithm 1) in its reduced dense form:
-//   (P + sigma I + A' R A) xt = sigma x - q + A'(R z - y),  zt = A xt,
-//   x <- alpha xt + (1-alpha) x,  z <- clip(alpha zt + (1-alpha) z + y/R),  y <- y + R(alpha zt + (1-alpha) z_prev - z)
-// with R = diag(rho_i), rho_i = 1e3 rho on equality rows.  rho is re-balanced from the residual
-// ratio every 50 iterations.
-int solveDenseQP(int n, int m, const std::vector<double>& P, const std::vector<double>& q, const std::vector<double>& A_in,
-                 const std::vector<double>& l_in, const std::vector<double>& u_in, std::vector<double>& x, double eps, int maxIter) {
-    const double sigma = 1e-6, alpha = 1.6;
-    // row equilibration: every constraint row scaled to unit infinity norm (the continuity rows carry
-    // dt^4 factors), so one tolerance means the same thing on every row
-    std::vector<double> A(A_in), l(l_in), u(u_in);
-    for (int r = 0; r < m; ++r) {
-        double mx = 0;
-        for (int i = 0; i < n; ++i) mx = std::max(mx, std::fabs(A[(size_t)r * n + i]));
-        if (mx > 0) {
-            const double e = 1.0 / mx;
-            for (int i = 0; i < n; ++i) A[(size_t)r * n + i] *= e;
-            l[r] *= e;
-            u[r] *= e;
-        }
+// Strictly convex QP  min 1/2 w'Hw + c'w  s.t.  a_k'w >= b_k  by the dual active-set method of
+// Goldfarb & Idnani (Math. Programming 27, 1983): start at the unconstrained minimum, add the most
+// violated constraint, step in the primal/dual space, drop constraints whose multiplier reaches 0.
+// The working-set systems are solved from H^-1 directly (dimension <= 2 x segments here), not with
+// incremental factor updates.  Returns iterations, -1 numerical failure, -2 infeasible.
+static int dualActiveSet(int nf, const std::vector<double>& Hinv, const std::vector<double>& c, int nc,
+                         const std::vector<double>& Acon, const std::vector<double>& bcon, std::vector<double>& w) {
+    w.assign(nf, 0.0);
+    for (int i = 0; i < nf; ++i) {
+        double s = 0;
+        for (int j = 0; j < nf; ++j) s += Hinv[(size_t)i * nf + j] * c[j];
+        w[i] = -s;
     }
-    double rho = 0.1;
-    std::vector<double> rhoV(m), z(m, 0.0), y(m, 0.0), K, rhs(n), zt(m), zprev(m), Ax(m), Px(n), Aty(n);
-    x.assign(n, 0.0);
-    auto factor = [&]() -> bool {
-        for (int i = 0; i < m; ++i) rhoV[i] = (l[i] == u[i]) ? 1e3 * rho : rho;
-        K.assign((size_t)n * n, 0.0);
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j <= i; ++j) K[(size_t)i * n + j] = P[(size_t)i * n + j];
-        for (int i = 0; i < n; ++i) K[(size_t)i * n + i] += sigma;
-        for (int r = 0; r < m; ++r) {
-            const double* a = &A[(size_t)r * n];
-            for (int i = 0; i < n; ++i) {
-                if (a[i] == 0.0) continue;
-                const double ai = rhoV[r] * a[i];
-                for (int j = 0; j <= i; ++j) K[(size_t)i * n + j] += ai * a[j];
-            }
-        }
-        return cholesky(K, n);
+    std::vector<int> act;          // working set (constraint indices)
+    std::vector<double> u;         // their multipliers
+    std::vector<char> inAct(nc, 0);
+    std::vector<double> Hn(nf), z(nf), r, M, HN, rhs;
+    auto slack = [&](int k) {
+        double s = -bcon[k];
+        for (int i = 0; i < nf; ++i) s += Acon[(size_t)k * nf + i] * w[i];
+        return s;
     };
-    if (!factor()) return -1;
-    for (int it = 1; it <= maxIter; ++it) {
-        for (int i = 0; i < n; ++i) rhs[i] = sigma * x[i] - q[i];
-        for (int r = 0; r < m; ++r) {
-            const double c = rhoV[r] * z[r] - y[r];
-            const double* a = &A[(size_t)r * n];
-            for (int i = 0; i < n; ++i) rhs[i] += a[i] * c;
+    const int maxIter = 50 * (nc + nf) + 100;
+    int iter = 0;
+    for (;;) {
+        int ip = -1;
+        double worst = 0;
+        for (int k = 0; k < nc; ++k) {
+            if (inAct[k]) continue;
+            const double s = slack(k), tol = 1e-9 * (1.0 + std::fabs(bcon[k]));
+            if (s < -tol && s < worst) { worst = s; ip = k; }
         }
-        cholSolve(K, n, rhs);  // rhs = xt
-        for (int r = 0; r < m; ++r) {
-            const double* a = &A[(size_t)r * n];
-            double s = 0;
-            for (int i = 0; i < n; ++i) s += a[i] * rhs[i];
-            zt[r] = s;
-        }
-        for (int i = 0; i < n; ++i) x[i] = alpha * rhs[i] + (1 - alpha) * x[i];
-        zprev = z;
-        for (int r = 0; r < m; ++r) {
-            const double v = alpha * zt[r] + (1 - alpha) * zprev[r];
-            z[r] = std::min(std::max(v + y[r] / rhoV[r], l[r]), u[r]);
-            y[r] += rhoV[r] * (v - z[r]);
-        }
-        if (it % 10 == 0 || it == maxIter) {
-            // residuals: primal ||Ax - z||inf, dual ||Px + q + A'y||inf
-            double rp = 0, rd = 0, nAx = 0, nz = 0, nPx = 0, nAty = 0, nq = 0;
-            for (int r = 0; r < m; ++r) {
-                const double* a = &A[(size_t)r * n];
+        if (ip < 0) return iter;
+        const double* np = &Acon[(size_t)ip * nf];
+        double uq = 0.0, sip = worst;
+        for (;;) {
+            if (++iter > maxIter) return -1;
+            const int q = (int)act.size();
+            for (int i = 0; i < nf; ++i) {
                 double s = 0;
-                for (int i = 0; i < n; ++i) s += a[i] * x[i];
-                Ax[r] = s;
-                rp = std::max(rp, std::fabs(s - z[r]));
-                nAx = std::max(nAx, std::fabs(s));
-                nz = std::max(nz, std::fabs(z[r]));
+                for (int j = 0; j < nf; ++j) s += Hinv[(size_t)i * nf + j] * np[j];
+                Hn[i] = s;
             }
-            for (int i = 0; i < n; ++i) {
-                double s = 0, t = 0;
-                for (int j = 0; j < n; ++j) s += P[(size_t)i * n + j] * x[j];
-                for (int r = 0; r < m; ++r) t += A[(size_t)r * n + i] * y[r];
-                Px[i] = s; Aty[i] = t;
-                rd = std::max(rd, std::fabs(s + q[i] + t));
-                nPx = std::max(nPx, std::fabs(s));
-                nAty = std::max(nAty, std::fabs(t));
-                nq = std::max(nq, std::fabs(q[i]));
-            }
-            const double ep = eps + eps * std::max(nAx, nz), ed = eps + eps * std::max(std::max(nPx, nAty), nq);
-            if (rp <= ep && rd <= ed) return it;
-            if (it % 50 == 0) {
-                const double num = rp / std::max(std::max(nAx, nz), 1e-12), den = rd / std::max(std::max(std::max(nPx, nAty), nq), 1e-12);
-                const double ratio = std::sqrt(num / std::max(den, 1e-30));
-                if (ratio > 5.0 || ratio < 0.2) {
-                    rho = std::min(std::max(rho * ratio, 1e-6), 1e6);
-                    if (!factor()) return -1;
+            double npHn = 0;
+            for (int i = 0; i < nf; ++i) npHn += np[i] * Hn[i];
+            z = Hn;
+            r.assign(q, 0.0);
+            if (q > 0) {
+                // HN = Hinv N (nf x q), M = N' Hinv N, rhs = N' Hn
+                HN.assign((size_t)nf * q, 0.0);
+                for (int j = 0; j < q; ++j) {
+                    const double* nj = &Acon[(size_t)act[j] * nf];
+                    for (int i = 0; i < nf; ++i) {
+                        double s = 0;
+                        for (int k = 0; k < nf; ++k) s += Hinv[(size_t)i * nf + k] * nj[k];
+                        HN[(size_t)i * q + j] = s;
+                    }
+                }
+                M.assign((size_t)q * q, 0.0);
+                rhs.assign(q, 0.0);
+                for (int a = 0; a < q; ++a) {
+                    const double* na = &Acon[(size_t)act[a] * nf];
+                    for (int b = 0; b <= a; ++b) {
+                        double s = 0;
+                        for (int i = 0; i < nf; ++i) s += na[i] * HN[(size_t)i * q + b];
+                        M[(size_t)a * q + b] = s;
+                    }
+                    double s = 0;
+                    for (int i = 0; i < nf; ++i) s += na[i] * Hn[i];
+                    rhs[a] = s;
+                }
+                if (!cholesky(M, q)) return -1;
+                cholSolve(M, q, rhs.data());
+                r = rhs;
+                for (int i = 0; i < nf; ++i) {
+                    double s = 0;
+                    for (int j = 0; j < q; ++j) s += HN[(size_t)i * q + j] * r[j];
+                    z[i] -= s;
                 }
             }
+            double zn = 0;
+            for (int i = 0; i < nf; ++i) zn += z[i] * np[i];
+            double t1 = INFINITY, t2 = INFINITY;
+            int drop = -1;
+            for (int j = 0; j < q; ++j)
+                if (r[j] > 0 && u[j] / r[j] < t1) { t1 = u[j] / r[j]; drop = j; }
+            if (zn > 1e-11 * npHn) t2 = -sip / zn;
+            const double t = t1 < t2 ? t1 : t2;
+            if (!(t < INFINITY)) return -2;                     // no step possible: infeasible
+            for (int j = 0; j < q; ++j) u[j] -= t * r[j];
+            uq += t;
+            if (t2 < INFINITY) for (int i = 0; i < nf; ++i) w[i] += t * z[i];
+            if (t == t2) {                                       // full step: the constraint becomes active
+                act.push_back(ip); u.push_back(uq); inAct[ip] = 1;
+                break;
+            }
+            inAct[act[drop]] = 0;                                // partial step: drop the blocking constraint
+            act.erase(act.begin() + drop);
+            u.erase(u.begin() + drop);
+            sip = slack(ip);
         }
     }
-    return maxIter;
+}
+
+// min 1/2 x'Px + q'x  s.t.  l <= Ax <= u.  Rows with l == u are eliminated with an orthonormal
+// null-space basis (Householder QR of A_eq'): for the min-snap problem that leaves 2 free
+// coefficients per segment, a tiny strictly convex QP in which only the corridor boxes remain —
+// solved exactly by the dual active-set method above.  Returns iterations >= 0, -1 numerical
+// failure (rank-deficient equalities), -2 infeasible.
+int solveDenseQP(int n, int m, const std::vector<double>& P, const std::vector<double>& q, const std::vector<double>& A,
+                 const std::vector<double>& l, const std::vector<double>& u, std::vector<double>& x) {
+    std::vector<int> eqRows, inRows;
+    for (int r = 0; r < m; ++r) {
+        if (l[r] > u[r]) return -2;
+        if (l[r] == u[r]) eqRows.push_back(r);
+        else if (l[r] > -INFINITY || u[r] < INFINITY) inRows.push_back(r);
+    }
+    const int me = (int)eqRows.size(), mi = (int)inRows.size();
+    if (me > n) return -1;
+    // Mt = A_eq' (n x me), rows scaled to unit infinity norm first (continuity rows carry dt^4)
+    std::vector<double> Mt((size_t)n * me), beq(me);
+    for (int j = 0; j < me; ++j) {
+        const double* a = &A[(size_t)eqRows[j] * n];
+        double mx = 0;
+        for (int i = 0; i < n; ++i) mx = std::max(mx, std::fabs(a[i]));
+        if (!(mx > 0)) return -1;
+        for (int i = 0; i < n; ++i) Mt[(size_t)i * me + j] = a[i] / mx;
+        beq[j] = l[eqRows[j]] / mx;
+    }
+    // Householder QR: Mt = Q R; Q accumulated explicitly (n x n)
+    std::vector<double> Q((size_t)n * n, 0.0), v(n);
+    for (int i = 0; i < n; ++i) Q[(size_t)i * n + i] = 1.0;
+    for (int j = 0; j < me; ++j) {
+        double nrm = 0;
+        for (int i = j; i < n; ++i) nrm += Mt[(size_t)i * me + j] * Mt[(size_t)i * me + j];
+        nrm = std::sqrt(nrm);
+        if (!(nrm > 1e-10)) return -1;                          // dependent equality rows
+        const double alpha = Mt[(size_t)j * me + j] > 0 ? -nrm : nrm;
+        for (int i = 0; i < n; ++i) v[i] = i < j ? 0.0 : Mt[(size_t)i * me + j];
+        v[j] -= alpha;
+        double vv = 0;
+        for (int i = j; i < n; ++i) vv += v[i] * v[i];
+        if (vv > 0) {
+            for (int c = j; c < me; ++c) {                      // Mt <- (I - 2vv'/v'v) Mt
+                double s = 0;
+                for (int i = j; i < n; ++i) s += v[i] * Mt[(size_t)i * me + c];
+                s *= 2.0 / vv;
+                for (int i = j; i < n; ++i) Mt[(size_t)i * me + c] -= s * v[i];
+            }
+            for (int rr = 0; rr < n; ++rr) {                    // Q <- Q (I - 2vv'/v'v)
+                double s = 0;
+                for (int i = j; i < n; ++i) s += Q[(size_t)rr * n + i] * v[i];
+                s *= 2.0 / vv;
+                for (int i = j; i < n; ++i) Q[(size_t)rr * n + i] -= s * v[i];
+            }
+        }
+    }
+    // particular solution x0 = Y R^-T beq  (A_eq = R'Q' => (Q'x)[:me] = R^-T beq)
+    std::vector<double> y(me), x0(n, 0.0);
+    for (int i = 0; i < me; ++i) {
+        double s = beq[i];
+        for (int k = 0; k < i; ++k) s -= Mt[(size_t)k * me + i] * y[k];
+        y[i] = s / Mt[(size_t)i * me + i];
+    }
+    for (int i = 0; i < n; ++i) {
+        double s = 0;
+        for (int k = 0; k < me; ++k) s += Q[(size_t)i * n + k] * y[k];
+        x0[i] = s;
+    }
+    const int nf = n - me;
+    x = x0;
+    if (nf == 0) {
+        for (int r : inRows) {
+            double s = 0;
+            for (int i = 0; i < n; ++i) s += A[(size_t)r * n + i] * x[i];
+            if (s < l[r] - 1e-9 || s > u[r] + 1e-9) return -2;
+        }
+        return 0;
+    }
+    // reduced problem in w: x = x0 + Z w, Z = Q[:, me:]
+    auto Zc = [&](int i, int k) { return Q[(size_t)i * n + me + k]; };
+    std::vector<double> PZ((size_t)n * nf, 0.0), H((size_t)nf * nf, 0.0), c(nf, 0.0), g(n, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const double pij = P[(size_t)i * n + j];
+            if (pij == 0.0) continue;
+            for (int k = 0; k < nf; ++k) PZ[(size_t)i * nf + k] += pij * Zc(j, k);
+            g[i] += pij * x0[j];
+        }
+    for (int i = 0; i < n; ++i) g[i] += q[i];
+    for (int a = 0; a < nf; ++a) {
+        for (int b = 0; b < nf; ++b) {
+            double s = 0;
+            for (int i = 0; i < n; ++i) s += Zc(i, a) * PZ[(size_t)i * nf + b];
+            H[(size_t)a * nf + b] = s;
+        }
+        double s = 0;
+        for (int i = 0; i < n; ++i) s += Zc(i, a) * g[i];
+        c[a] = s;
+    }
+    for (int a = 0; a < nf; ++a)
+        for (int b = 0; b < a; ++b) H[(size_t)a * nf + b] = H[(size_t)b * nf + a] = 0.5 * (H[(size_t)a * nf + b] + H[(size_t)b * nf + a]);
+    std::vector<double> Lh(H);
+    if (!cholesky(Lh, nf)) return -1;
+    std::vector<double> Hinv((size_t)nf * nf, 0.0), col(nf);
+    for (int k = 0; k < nf; ++k) {
+        std::fill(col.begin(), col.end(), 0.0);
+        col[k] = 1.0;
+        cholSolve(Lh, nf, col.data());
+        for (int i = 0; i < nf; ++i) Hinv[(size_t)i * nf + k] = col[i];
+    }
+    // inequality rows in w: lo <= (A_r Z) w + A_r x0 <= hi, as a'w >= b pairs
+    std::vector<double> Acon, bcon;
+    for (int r : inRows) {
+        std::vector<double> az(nf, 0.0);
+        double d0 = 0;
+        for (int i = 0; i < n; ++i) {
+            const double ai = A[(size_t)r * n + i];
+            if (ai == 0.0) continue;
+            d0 += ai * x0[i];
+            for (int k = 0; k < nf; ++k) az[k] += ai * Zc(i, k);
+        }
+        if (l[r] > -INFINITY) { Acon.insert(Acon.end(), az.begin(), az.end()); bcon.push_back(l[r] - d0); }
+        if (u[r] < INFINITY) { for (double& t : az) t = -t; Acon.insert(Acon.end(), az.begin(), az.end()); bcon.push_back(d0 - u[r]); }
+    }
+    std::vector<double> w;
+    const int it = dualActiveSet(nf, Hinv, c, (int)bcon.size(), Acon, bcon, w);
+    if (it < 0) return it;
+    for (int i = 0; i < n; ++i) {
+        double s = 0;
+        for (int k = 0; k < nf; ++k) s += Zc(i, k) * w[k];
+        x[i] = x0[i] + s;
+    }
+    (void)mi;
+    return it;
 }
 
 // ---- the min-snap problem -----------------------------------------------------------------
@@ -309,10 +448,8 @@ bool polyTrajSolver::solve() {
     bool ok = true;
     for (int a = 0; a < 3; ++a) {
         std::vector<double> x;
-        const int maxIter = 20000;
-        const int it = solveDenseQP(paramDim_, constraintNum_, P, q, A, l[a], u[a], x, 1e-7, maxIter);
-        if (it < 0) { ok = false; continue; }   // keep the stale solution, like the reference
-        if (it >= maxIter) ok = false;          // not converged (e.g. infeasible corridor): best iterate kept
+        const int it = solveDenseQP(paramDim_, constraintNum_, P, q, A, l[a], u[a], x);
+        if (it < 0) { ok = false; continue; }   // infeasible corridor / degenerate path: keep the stale solution, like the reference
         // PS.cpp:874-878: back to un-normalised local time
         for (size_t s = 0; s + 1 < path_.size(); ++s)
             for (int d = 0; d <= polyDegree_; ++d) x[s * (polyDegree_ + 1) + d] /= std::pow(desiredTime_[s + 1] - desiredTime_[s], d);
