@@ -194,7 +194,22 @@ int vigo_optimize(vigo_handle_t h, int B, int N, double* ctrl,
                   double* out_x, int32_t* out_status, double* out_fx,
                   int32_t* out_iters, int32_t* out_evals);
 
-/* ---- B-spline evaluation and the rebound-loop gates -------------------------------- */
+/* ---- B-spline fit, evaluation and the rebound-loop gates --------------------------- */
+
+/*
+ * Replaces: bspline::parameterizeToBspline (BS.cpp:74-138) as bsplineTraj::updatePath calls it
+ * (BT.cpp:314), for B paths of K waypoints each in one launch: least-squares solution of the
+ * (K+4)x(K+2) system [1 4 1]/6 | velocity rows | acceleration rows (three colPivHouseholderQr
+ * solves per path in the reference).  The factorisation depends on (K, ts) only; it is computed on
+ * the device at the first call with a new (K, ts) and cached in the handle.
+ *   points   double[B][K][3]   waypoints
+ *   conds    double[B][4][3]   start vel, end vel, start acc, end acc (the startEndConditions order of BT.cpp:290, BS.cpp:117-121);
+ *                              NULL => all zero
+ *   ctrl_out double[B][K+2][3] control points (the `ctrl` layout of vigo_optimize, N = K + 2)
+ * 4 <= K <= VIGO_MAX_CTRL_POINTS - 2 (the reference exit(0)s below 4 points, BS.cpp:83-87).
+ */
+int vigo_bspline_fit(vigo_handle_t h, int B, int K, double ts, const double* points,
+                     const double* conds, double* ctrl_out);
 
 /*
  * Replaces: bspline::at (BS.cpp:32-58) on bspline(3, ctrl, ts_ctrl) and its

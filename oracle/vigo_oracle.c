@@ -824,6 +824,82 @@ void vgo_bspline_at(int degree, int ncp, const double* cp, double ts, double t, 
     for (int a = 0; a < 3; ++a) out[a] = d[degree][a];
 }
 
+/* bspline::parameterizeToBspline, BS.cpp:74-138: the (K+4)x(K+2) system and its least-squares
+ * solution by column-pivoted Householder QR (the decomposition the reference asks Eigen for,
+ * BS.cpp:129-131; Eigen itself is absent here, so the pivot order is this file's own: largest
+ * remaining column norm, recomputed every step).  points [K][3], cond [4][3] (vel0, vel1, acc0,
+ * acc1), ctrl_out [K+2][3].  Returns 0, or -1 for K < 4 / ts <= 0 (the reference exit(0)s). */
+int vgo_bspline_fit(int K, double ts, const double* points, const double* cond, double* ctrl_out) {
+    if (ts <= 0 || K <= 3) return -1;
+    const int R = K + 4, Cn = K + 2;
+    double* A = (double*)calloc((size_t)R * Cn, sizeof(double));
+    double* b = (double*)calloc((size_t)R * 3, sizeof(double));
+    int* perm = (int*)malloc(sizeof(int) * Cn);
+    double* v = (double*)malloc(sizeof(double) * R);
+#define AT(r, c) A[(size_t)(r) * Cn + (c)]
+    for (int i = 0; i < K; ++i) {                       /* BS.cpp:102-104 */
+        AT(i, i) = (1 / 6.0) * 1; AT(i, i + 1) = (1 / 6.0) * 4; AT(i, i + 2) = (1 / 6.0) * 1;
+        for (int a = 0; a < 3; ++a) b[3 * i + a] = points[3 * i + a];
+    }
+    AT(K, 0) = (1 / 2.0 / ts) * -1; AT(K, 2) = (1 / 2.0 / ts) * 1;                    /* :106 */
+    AT(K + 1, K - 1) = (1 / 2.0 / ts) * -1; AT(K + 1, K + 1) = (1 / 2.0 / ts) * 1;    /* :107 */
+    AT(K + 2, 0) = (1 / ts / ts) * 1; AT(K + 2, 1) = (1 / ts / ts) * -2; AT(K + 2, 2) = (1 / ts / ts) * 1;              /* :108 */
+    AT(K + 3, K - 1) = (1 / ts / ts) * 1; AT(K + 3, K) = (1 / ts / ts) * -2; AT(K + 3, K + 1) = (1 / ts / ts) * 1;      /* :109 */
+    for (int i = 0; i < 4; ++i)
+        for (int a = 0; a < 3; ++a) b[3 * (K + i) + a] = cond ? cond[3 * i + a] : 0.0;    /* :119-123 */
+    for (int c = 0; c < Cn; ++c) perm[c] = c;
+    for (int c = 0; c < Cn; ++c) {
+        int best = c;
+        double bestn = -1;
+        for (int cc = c; cc < Cn; ++cc) {
+            double n2 = 0;
+            for (int r = c; r < R; ++r) n2 += AT(r, cc) * AT(r, cc);
+            if (n2 > bestn) { bestn = n2; best = cc; }
+        }
+        if (best != c) {
+            for (int r = 0; r < R; ++r) { double t = AT(r, c); AT(r, c) = AT(r, best); AT(r, best) = t; }
+            int t = perm[c]; perm[c] = perm[best]; perm[best] = t;
+        }
+        double nrm = sqrt(bestn);
+        if (nrm == 0) break;
+        double alpha = AT(c, c) > 0 ? -nrm : nrm;
+        double vn = 0;
+        for (int r = c; r < R; ++r) v[r] = AT(r, c);
+        v[c] -= alpha;
+        for (int r = c; r < R; ++r) vn += v[r] * v[r];
+        if (vn == 0) continue;
+        for (int cc = c; cc < Cn; ++cc) {
+            double sdot = 0;
+            for (int r = c; r < R; ++r) sdot += v[r] * AT(r, cc);
+            sdot = 2 * sdot / vn;
+            for (int r = c; r < R; ++r) AT(r, cc) -= sdot * v[r];
+        }
+        for (int a = 0; a < 3; ++a) {
+            double sdot = 0;
+            for (int r = c; r < R; ++r) sdot += v[r] * b[3 * r + a];
+            sdot = 2 * sdot / vn;
+            for (int r = c; r < R; ++r) b[3 * r + a] -= sdot * v[r];
+        }
+    }
+    for (int a = 0; a < 3; ++a) {
+        for (int r = Cn - 1; r >= 0; --r) {
+            double sacc = b[3 * r + a];
+            for (int cc = r + 1; cc < Cn; ++cc) sacc -= AT(r, cc) * v[cc];
+            v[r] = sacc / AT(r, r);
+        }
+        for (int r = 0; r < Cn; ++r) ctrl_out[3 * perm[r] + a] = v[r];
+    }
+#undef AT
+    free(A); free(b); free(perm); free(v);
+    return 0;
+}
+
+void vgo_bspline_fit_batch(int B, int K, double ts, const double* points, const double* conds, double* ctrl_out) {
+    for (int i = 0; i < B; ++i)
+        vgo_bspline_fit(K, ts, points + (size_t)i * K * 3, conds ? conds + (size_t)i * 12 : NULL,
+                        ctrl_out + (size_t)i * (K + 2) * 3);
+}
+
 void vgo_bspline_derivative(int degree, int ncp, const double* cp, double ts, double* out) {
     for (int i = 0; i < ncp - 1; ++i) {
         double den = knot(i + degree + 1, degree, ts) - knot(i + 1, degree, ts);

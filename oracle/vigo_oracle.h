@@ -101,6 +101,9 @@ void vgo_optimize_batch(const vigo_params_t* P, int B, int N, double* ctrl,
                         double* out_fx, int32_t* out_iters, int32_t* out_evals);
 
 /* BS.cpp:19-72: uniform B-spline of `degree` over ncp control points (rows of 3). */
+/* BS.cpp:74-138 (least-squares fit of waypoints + boundary conditions to control points) */
+int vgo_bspline_fit(int K, double ts, const double* points, const double* cond, double* ctrl_out);
+void vgo_bspline_fit_batch(int B, int K, double ts, const double* points, const double* conds, double* ctrl_out);
 void vgo_bspline_at(int degree, int ncp, const double* cp, double ts, double t, double out[3]);
 /* derivative control points (BS.cpp:64-72): out has ncp-1 rows */
 void vgo_bspline_derivative(int degree, int ncp, const double* cp, double ts, double* out);

@@ -179,6 +179,19 @@ def optimize_batch(P, batch, weights=None):
     return dict(ctrl=ctrl, x=x, status=status, fx=fx, iters=iters, evals=evals)
 
 
+def bspline_fit_batch(points, ts, conds=None):
+    """oracle vgo_bspline_fit_batch: points [B,K,3] (+ conds [B,4,3]) -> control points [B,K+2,3]"""
+    pts = _c(points, np.float64)
+    B, K, _ = pts.shape
+    cd = _c(conds, np.float64)
+    out = np.zeros((B, K + 2, 3))
+    O = oracle()
+    O.vgo_bspline_fit_batch.argtypes = [C.c_int, C.c_int, C.c_double, _dp, _dp, _dp]
+    O.vgo_bspline_fit_batch.restype = None
+    O.vgo_bspline_fit_batch(B, K, float(ts), _d(pts), _d(cd), _d(out))
+    return out
+
+
 def make_grid(world):
     """vgo_grid_t over a synth.World (keeps the numpy array alive via the returned tuple)."""
     vox = np.ascontiguousarray(world.voxels, dtype=np.uint8)

@@ -69,6 +69,26 @@ def test_fit_of_testBsplineFit_points_reproduces_them():
     assert np.allclose(A.T @ (A @ ctrl - rhs), 0, atol=1e-9)            # normal equations hold
 
 
+def test_oracle_fit_is_the_least_squares_solution():
+    """vgo_bspline_fit (BS.cpp:74-138, column-pivoted Householder) against numpy's SVD least squares,
+    on the reference test program's points and on random paths with non-zero boundary conditions"""
+    pts = FIX["fit_points"][None]
+    got = ol.bspline_fit_batch(pts, 0.1)
+    ref = synth.fit_control_points(pts, ts=0.1)
+    assert np.abs(got - ref).max() <= 1e-12
+    rng = np.random.default_rng(5)
+    for K in (4, 5, 30, 62, 120):
+        p = rng.normal(size=(4, K, 3)) * 3
+        cd = rng.normal(size=(4, 4, 3))
+        got = ol.bspline_fit_batch(p, 0.2, cd)
+        A = synth.fit_matrix(K, 0.2)
+        rhs = np.concatenate([p, cd], 1)
+        ref = np.stack([np.linalg.lstsq(A, rhs[b], rcond=None)[0] for b in range(4)])
+        assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max()
+    out = np.zeros((5, 3))
+    assert ol.oracle().vgo_bspline_fit(3, C.c_double(0.2), ol._d(np.zeros((3, 3))), None, ol._d(out)) == -1
+
+
 def test_sample_clock_accumulates():
     n = ol.oracle().vgo_sample_times(5.8, 0.05, None, 0)
     buf = np.zeros(n)

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "vigo_guides_unknown": (_i, [_vp, _i64, _vp, _vp]),
     "vigo_cost_grad": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "vigo_optimize": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vigo_bspline_fit": (_i, [_vp, _i, _i, _d, _vp, _vp, _vp]),
     "vigo_bspline_eval": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "vigo_traj_collision": (_i, [_vp, _i, _i, _vp, _d, _vp, _vp]),
     "vigo_traj_dynamic_collision": (_i, [_vp, _i, _i, _vp, _d, _vp, _vp, _i, _vp]),

@@ -167,6 +167,7 @@ int vigo_destroy(vigo_handle_t h) {
     (void)hipSetDevice(h->device);
     if (h->grid_planes) (void)hipFree(h->grid_planes);
     if (h->esdf) (void)hipFree(h->esdf);
+    if (h->fit_pinvT) (void)hipFree(h->fit_pinvT);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->dc_dev) (void)hipFree(h->dc_dev);
     delete h;
@@ -316,7 +317,34 @@ int vigo_optimize(vigo_handle_t h, int B, int N, double* ctrl, const int32_t* gu
     return VIGO_OK;
 }
 
-/* ---- B-spline evaluation and gates ----------------------------------------------------- */
+/* ---- B-spline fit, evaluation and gates ------------------------------------------------- */
+
+int vigo_bspline_fit(vigo_handle_t h, int B, int K, double ts, const double* points, const double* conds, double* ctrl_out) {
+    if (!h) return VIGO_ERR_INVALID_ARG;
+    if (B < 0 || !(ts > 0) || (B > 0 && (!points || !ctrl_out))) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_bspline_fit: bad argument");
+    // bspline.cpp:83-87 needs at least 4 points; K + 2 control points must fit the solver's range
+    if (K < 4 || K + 2 > VIGO_MAX_CTRL_POINTS) return fail(h, VIGO_ERR_UNSUPPORTED_N, "K outside [4, VIGO_MAX_CTRL_POINTS - 2]");
+    if (h->fit_K != K || h->fit_ts != ts) {
+        // one-off per (K, ts): factorise A on the device, keep the least-squares operator
+        const size_t need = vigo::fit_pinv_doubles(K);
+        if (need > h->fit_capacity) {
+            if (h->fit_pinvT) (void)hipFree(h->fit_pinvT);
+            h->fit_pinvT = nullptr;
+            h->fit_capacity = 0;
+            h->fit_K = 0;
+            VIGO_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->fit_pinvT), need * sizeof(double)));
+            h->fit_capacity = need;
+        }
+        int rc = ensure_scratch(h, vigo::fit_work_doubles(K) * sizeof(double));
+        if (rc) return rc;
+        h->fit_K = 0;
+        VIGO_HIP(h, (hipError_t)vigo::launch_fit_setup(h->stream, K, ts, static_cast<double*>(h->scratch), h->fit_pinvT));
+        h->fit_K = K;
+        h->fit_ts = ts;
+    }
+    VIGO_HIP(h, (hipError_t)vigo::launch_bspline_fit(h->stream, B, K, h->fit_pinvT, points, conds, ctrl_out));
+    return VIGO_OK;
+}
 
 int vigo_bspline_eval(vigo_handle_t h, int B, int N, const double* ctrl, int deriv, int T,
                       const double* times, double* out) {

@@ -1,0 +1,188 @@
+// vigo_fit.hip — batched bspline::parameterizeToBspline (bspline.cpp:74-138): waypoints + start/end
+// velocity/acceleration -> cubic B-spline control points, the step right before the optimizer
+// (bsplineTraj::updatePath, bsplineTraj.cpp:290-323).
+//
+// The reference builds the (K+4) x (K+2) system A (rows [1 4 1]/6 per waypoint, two velocity rows
+// [-1 0 1]/(2 ts), two acceleration rows [1 -2 1]/ts^2) and solves min |A x - b| three times with
+// Eigen's colPivHouseholderQr.  A depends on (K, ts) only, never on the data, so the batch shares
+// one factorisation:
+//   k_fit_setup   (once per (K, ts), one workgroup, all on the device) Householder QR of [A | I]
+//                 -> R, Q'; back-substitution of every column of Q' gives the least-squares
+//                 operator A+ = R^-1 Q'[:K+2] stored TRANSPOSED, pinvT[j][row], so that lanes
+//                 (rows) read consecutive addresses;
+//   k_bspline_fit one wave per workgroup, lane <-> control point (row of A+): the lane keeps its
+//                 row of A+ in registers for all trajectories of its grid-stride loop, the K+4
+//                 input rows of a trajectory are staged through LDS (coalesced HBM read, broadcast
+//                 LDS reads), output [K+2][3] written coalesced.  HBM-bound:
+//                 (2K + 6) * 24 algorithmic bytes per trajectory.
+// fp64, -ffp-contract=off, sums in index order: deterministic, batch-invariant.
+#include "vigo_internal.hpp"
+
+namespace vigo {
+namespace {
+
+constexpr int kSetupThreads = 256;
+constexpr int kMaxRows = VIGO_MAX_CTRL_POINTS + 2;  // R = K + 4 <= N_max + 2
+
+__device__ __forceinline__ double fit_entry(int r, int c, int K, double ts) {
+    if (r < K) {  // BS.cpp:102-104
+        const int d = c - r;
+        return d == 0 ? 1 / 6.0 : (d == 1 ? 4 / 6.0 : (d == 2 ? 1 / 6.0 : 0.0));
+    }
+    const int base = (r == K || r == K + 2) ? 0 : K - 1;  // BS.cpp:106-109
+    const int d = c - base;
+    if (d < 0 || d > 2) return 0.0;
+    if (r < K + 2) return d == 0 ? -1 / 2.0 / ts : (d == 2 ? 1 / 2.0 / ts : 0.0);
+    return d == 1 ? -2 / ts / ts : 1 / ts / ts;
+}
+
+// deterministic block sum (fixed tree)
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int s = kSetupThreads / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const double out = red[0];
+    __syncthreads();
+    return out;
+}
+
+// W: R x (C + R) row-major work matrix in global memory, [A | I] -> [R | Q'].
+__global__ void __launch_bounds__(kSetupThreads) k_fit_setup(int K, double ts, double* __restrict__ W,
+                                                             double* __restrict__ pinvT) {
+    const int R = K + 4, C = K + 2, Wc = C + R;
+    const int tid = threadIdx.x;
+    __shared__ double v[kMaxRows];
+    __shared__ double red[kSetupThreads];
+    for (int idx = tid; idx < R * Wc; idx += kSetupThreads) {
+        const int r = idx / Wc, c = idx % Wc;
+        W[idx] = c < C ? fit_entry(r, c, K, ts) : ((c - C == r) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    for (int c = 0; c < C; ++c) {
+        double part = 0.0;
+        for (int r = c + tid; r < R; r += kSetupThreads) {
+            const double a = W[(size_t)r * Wc + c];
+            v[r - c] = a;
+            part += a * a;
+        }
+        const double nrm = sqrt(block_sum(part, red));
+        if (nrm == 0.0) continue;  // cannot happen for K >= 4 (A has full column rank)
+        const double head = v[0];
+        const double alpha = head > 0 ? -nrm : nrm;
+        __syncthreads();
+        if (tid == 0) v[0] = head - alpha;
+        __syncthreads();
+        part = 0.0;
+        for (int r = tid; r < R - c; r += kSetupThreads) part += v[r] * v[r];
+        const double vn = block_sum(part, red);
+        if (vn != 0.0) {
+            for (int cc = c + tid; cc < Wc; cc += kSetupThreads) {  // column cc <- (I - 2 v v'/v'v) column cc
+                double s = 0.0;
+                for (int r = c; r < R; ++r) s += v[r - c] * W[(size_t)r * Wc + cc];
+                s = 2.0 * s / vn;
+                for (int r = c; r < R; ++r) W[(size_t)r * Wc + cc] -= s * v[r - c];
+            }
+        }
+        __syncthreads();
+    }
+    // x_j = R^-1 Q'[:C, j] for every column j of Q'; pinvT[j][row] = x_j[row]
+    for (int j = tid; j < R; j += kSetupThreads) {
+        double* x = pinvT + (size_t)j * C;
+        for (int r = C - 1; r >= 0; --r) {
+            double s = W[(size_t)r * Wc + C + j];
+            for (int cc = r + 1; cc < C; ++cc) s -= W[(size_t)r * Wc + cc] * x[cc];
+            x[r] = s / W[(size_t)r * Wc + r];
+        }
+    }
+}
+
+// rhs row j of trajectory b: waypoint j (j < K) or boundary condition j - K (zero when conds == NULL)
+__device__ __forceinline__ double fit_rhs(const double* __restrict__ points, const double* __restrict__ conds,
+                                          size_t b, int K, int i) {
+    if (i < 3 * K) return points[b * 3 * (size_t)K + i];
+    return conds ? conds[b * 12 + (i - 3 * K)] : 0.0;
+}
+
+// C <= 64: lane <-> control point, its row of A+ in registers (RMAX >= K + 4)
+template <int RMAX>
+__global__ void __launch_bounds__(64) k_bspline_fit_reg(int B, int K, const double* __restrict__ pinvT,
+                                                        const double* __restrict__ points,
+                                                        const double* __restrict__ conds, double* __restrict__ out) {
+    const int R = K + 4, C = K + 2;
+    const int row = threadIdx.x;
+    __shared__ double in[RMAX * 3];
+    double P[RMAX];
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) P[j] = (j < R && row < C) ? pinvT[(size_t)j * C + row] : 0.0;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        for (int i = threadIdx.x; i < 3 * R; i += 64) in[i] = fit_rhs(points, conds, (size_t)b, K, i);
+        __syncthreads();
+        double ax = 0.0, ay = 0.0, az = 0.0;
+#pragma unroll
+        for (int j = 0; j < RMAX; ++j) {
+            if (j < R) {
+                ax += P[j] * in[3 * j];
+                ay += P[j] * in[3 * j + 1];
+                az += P[j] * in[3 * j + 2];
+            }
+        }
+        if (row < C) {
+            double* dst = out + ((size_t)b * C + row) * 3;
+            dst[0] = ax; dst[1] = ay; dst[2] = az;
+        }
+        __syncthreads();
+    }
+}
+
+// any K: one 256-thread workgroup per trajectory, rows strided, A+ read from L2 (same sums, same order)
+__global__ void __launch_bounds__(256) k_bspline_fit_gen(int B, int K, const double* __restrict__ pinvT,
+                                                         const double* __restrict__ points,
+                                                         const double* __restrict__ conds, double* __restrict__ out) {
+    const int R = K + 4, C = K + 2;
+    __shared__ double in[kMaxRows * 3];
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        for (int i = threadIdx.x; i < 3 * R; i += 256) in[i] = fit_rhs(points, conds, (size_t)b, K, i);
+        __syncthreads();
+        for (int row = threadIdx.x; row < C; row += 256) {
+            double ax = 0.0, ay = 0.0, az = 0.0;
+            for (int j = 0; j < R; ++j) {
+                const double p = pinvT[(size_t)j * C + row];
+                ax += p * in[3 * j];
+                ay += p * in[3 * j + 1];
+                az += p * in[3 * j + 2];
+            }
+            double* dst = out + ((size_t)b * C + row) * 3;
+            dst[0] = ax; dst[1] = ay; dst[2] = az;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+size_t fit_work_doubles(int K) { return (size_t)(K + 4) * (size_t)(2 * K + 6); }
+size_t fit_pinv_doubles(int K) { return (size_t)(K + 4) * (size_t)(K + 2); }
+
+int launch_fit_setup(hipStream_t s, int K, double ts, double* work, double* pinvT) {
+    hipLaunchKernelGGL(k_fit_setup, dim3(1), dim3(kSetupThreads), 0, s, K, ts, work, pinvT);
+    return (int)hipGetLastError();
+}
+
+int launch_bspline_fit(hipStream_t s, int B, int K, const double* pinvT, const double* points, const double* conds,
+                       double* out) {
+    if (B <= 0) return hipSuccess;
+    const int grid = B < 4096 ? B : 4096;  // 16 waves per CU worth of workgroups, grid-stride beyond
+    if (K + 4 <= 36)
+        hipLaunchKernelGGL((k_bspline_fit_reg<36>), dim3(grid), dim3(64), 0, s, B, K, pinvT, points, conds, out);
+    else if (K + 2 <= 64)  // one lane per control point: C = K + 2 rows must fit the wave
+        hipLaunchKernelGGL((k_bspline_fit_reg<66>), dim3(grid), dim3(64), 0, s, B, K, pinvT, points, conds, out);
+    else
+        hipLaunchKernelGGL(k_bspline_fit_gen, dim3(grid), dim3(256), 0, s, B, K, pinvT, points, conds, out);
+    return (int)hipGetLastError();
+}
+
+}  // namespace vigo

@@ -101,6 +101,12 @@ int launch_box_points(hipStream_t s, const GridView& g, int64_t M, const double*
                       double map_res, uint8_t* out);
 int launch_esdf_query(hipStream_t s, const EsdfView& e, int64_t Q, const double* pts,
                       double* out_dist, double* out_grad);
+// batched B-spline fit (vigo_fit.hip): one-off device factorisation per (K, ts), then the fit
+size_t fit_work_doubles(int K);
+size_t fit_pinv_doubles(int K);
+int launch_fit_setup(hipStream_t s, int K, double ts, double* work, double* pinvT);
+int launch_bspline_fit(hipStream_t s, int B, int K, const double* pinvT, const double* points,
+                       const double* conds, double* out);
 
 }  // namespace vigo
 
@@ -122,6 +128,11 @@ struct vigo_context {
     size_t esdf_capacity = 0;
     vigo::EsdfView esdf_view{};
     bool has_esdf = false;
+    // least-squares operator of the B-spline fit for (fit_K, fit_ts), transposed (vigo_fit.hip)
+    double* fit_pinvT = nullptr;
+    size_t fit_capacity = 0;   // doubles
+    int fit_K = 0;
+    double fit_ts = 0.0;
     // scratch (sample-time tables, corridor checkpoints, staging of *_host calls)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;

@@ -91,6 +91,9 @@ public:
     bool makePlan(nav_msgs::Path& trajectory, bool yaw = true);
     /* all planners must share one map object; returns per-planner success like makePlan() */
     static std::vector<bool> makePlanBatch(const std::vector<bsplineTraj*>& planners);
+    /* updatePath() for many planners at once: the least-squares fits run as one device launch */
+    static std::vector<bool> updatePathBatch(const std::vector<bsplineTraj*>& planners, const std::vector<nav_msgs::Path>& paths,
+                                             const std::vector<std::vector<Eigen::Vector3d>>& startEndConditions);
     void clear();
     void findCollisionSeg(const Eigen::MatrixXd& controlPoints, std::vector<std::pair<int, int>>& collisionSeg);
     bool pathSearch(std::vector<std::pair<int, int>>& collisionSeg, std::vector<std::vector<Eigen::Vector3d>>& paths);
@@ -141,6 +144,8 @@ private:
     void reboundBegin(Rebound& r);
     /* one pass of the loop body of BT.cpp:619-681 given the gate results; sets r.done/ok/needOptimize */
     void reboundStep(Rebound& r, bool hasCollision, bool hasDynamicCollision, bool timedOut);
+    bool prepareFitPoints(const nav_msgs::Path& adjustedPath, std::vector<Eigen::Vector3d>& adjustedCurveFitPoints);
+    void installControlPoints(const Eigen::MatrixXd& controlPoints, const std::vector<Eigen::Vector3d>& adjustedCurveFitPoints);
     static void solveBatch(const std::vector<bsplineTraj*>& ps);   // one vigo_optimize for all
     static void gateBatch(const std::vector<bsplineTraj*>& ps, std::vector<uint8_t>& col, std::vector<uint8_t>& dyn);
 };

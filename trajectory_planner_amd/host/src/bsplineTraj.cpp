@@ -206,8 +206,9 @@ bool bsplineTraj::fillPath(const nav_msgs::Path& path, nav_msgs::Path& adjustedP
     return true;
 }
 
-// BT.cpp:290-323
-bool bsplineTraj::updatePath(const nav_msgs::Path& adjustedPath, const std::vector<Eigen::Vector3d>& startEndConditions) {
+// BT.cpp:290-312: everything of updatePath() before the fit — goal check, path-length adjustment,
+// filling short paths, clear() — leaving the curve-fit points
+bool bsplineTraj::prepareFitPoints(const nav_msgs::Path& adjustedPath, std::vector<Eigen::Vector3d>& adjustedCurveFitPoints) {
     if (adjustedPath.poses.empty() || !map_) return false;
     Eigen::Vector3d goal(adjustedPath.poses.back().pose.position.x, adjustedPath.poses.back().pose.position.y,
                          adjustedPath.poses.back().pose.position.z);
@@ -227,11 +228,12 @@ bool bsplineTraj::updatePath(const nav_msgs::Path& adjustedPath, const std::vect
         }
     }
     this->clear();
-    std::vector<Eigen::Vector3d> adjustedCurveFitPoints;
     this->pathMsgToEigenPoints(inputPath, adjustedCurveFitPoints);
-    Eigen::MatrixXd controlPoints;
-    if (!trajPlanner::bspline::parameterizeToBspline(this->controlPointsTs_, adjustedCurveFitPoints, startEndConditions, controlPoints))
-        return false;  // the reference exit(0)s here (bspline.cpp:80-91)
+    return true;
+}
+
+// BT.cpp:315-322
+void bsplineTraj::installControlPoints(const Eigen::MatrixXd& controlPoints, const std::vector<Eigen::Vector3d>& adjustedCurveFitPoints) {
     this->optData_.controlPoints = controlPoints;
     int controlPointNum = controlPoints.cols();
     this->optData_.guidePoints.assign(controlPointNum, {});
@@ -239,7 +241,63 @@ bool bsplineTraj::updatePath(const nav_msgs::Path& adjustedPath, const std::vect
     this->optData_.findGuidePoint.assign(controlPointNum, false);
     this->init_ = true;
     this->inputPathVis_ = adjustedCurveFitPoints;
+}
+
+// BT.cpp:290-323
+bool bsplineTraj::updatePath(const nav_msgs::Path& adjustedPath, const std::vector<Eigen::Vector3d>& startEndConditions) {
+    std::vector<Eigen::Vector3d> adjustedCurveFitPoints;
+    if (!this->prepareFitPoints(adjustedPath, adjustedCurveFitPoints)) return false;
+    Eigen::MatrixXd controlPoints;
+    if (!trajPlanner::bspline::parameterizeToBspline(this->controlPointsTs_, adjustedCurveFitPoints, startEndConditions, controlPoints))
+        return false;  // the reference exit(0)s here (bspline.cpp:80-91)
+    this->installControlPoints(controlPoints, adjustedCurveFitPoints);
     return true;
+}
+
+// updatePath() for many planners: the host prologue per planner, then ONE vigo_bspline_fit launch
+// per group of equal waypoint count (bspline::parameterizeToBspline, bspline.cpp:74-138, batched).
+std::vector<bool> bsplineTraj::updatePathBatch(const std::vector<bsplineTraj*>& planners, const std::vector<nav_msgs::Path>& paths,
+                                               const std::vector<std::vector<Eigen::Vector3d>>& startEndConditions) {
+    std::vector<bool> ok(planners.size(), false);
+    if (paths.size() != planners.size() || startEndConditions.size() != planners.size()) return ok;
+    std::vector<std::vector<Eigen::Vector3d>> fitPts(planners.size());
+    std::vector<bool> ready(planners.size(), false);
+    for (size_t i = 0; i < planners.size(); ++i)
+        ready[i] = startEndConditions[i].size() == 4 && planners[i]->prepareFitPoints(paths[i], fitPts[i]) && fitPts[i].size() > 3;
+    std::vector<bool> doneMask(planners.size(), false);
+    for (size_t a = 0; a < planners.size(); ++a) {
+        if (doneMask[a] || !ready[a]) continue;
+        const int K = (int)fitPts[a].size();
+        const double ts = planners[a]->controlPointsTs_;
+        std::vector<size_t> grp;
+        for (size_t b = a; b < planners.size(); ++b)
+            if (!doneMask[b] && ready[b] && (int)fitPts[b].size() == K && planners[b]->controlPointsTs_ == ts) { grp.push_back(b); doneMask[b] = true; }
+        bsplineTraj* lead = planners[a];
+        if (K + 2 > VIGO_MAX_CTRL_POINTS || !lead->syncDevice()) continue;
+        const int B = (int)grp.size();
+        std::vector<double> pts((size_t)B * K * 3), cond((size_t)B * 12), ctrl((size_t)B * (K + 2) * 3);
+        for (int b = 0; b < B; ++b) {
+            for (int i = 0; i < K; ++i)
+                for (int q = 0; q < 3; ++q) pts[((size_t)b * K + i) * 3 + q] = fitPts[grp[b]][i](q);
+            for (int i = 0; i < 4; ++i)
+                for (int q = 0; q < 3; ++q) cond[((size_t)b * 4 + i) * 3 + q] = startEndConditions[grp[b]][i](q);
+        }
+        DevBuf dPts, dCond, dCtrl;
+        if (!dPts.upload(pts.data(), pts.size() * 8) || !dCond.upload(cond.data(), cond.size() * 8) || !dCtrl.alloc(ctrl.size() * 8)) continue;
+        if (vigo_bspline_fit(lead->dev_, B, K, ts, (const double*)dPts.p, (const double*)dCond.p, (double*)dCtrl.p) != VIGO_OK) {
+            cout << "[BsplineTraj]: vigo_bspline_fit failed: " << vigo_last_error(lead->dev_) << endl;
+            continue;
+        }
+        if (hipDeviceSynchronize() != hipSuccess || !dCtrl.download(ctrl.data(), ctrl.size() * 8)) continue;
+        for (int b = 0; b < B; ++b) {
+            Eigen::MatrixXd controlPoints;
+            controlPoints.resize(3, K + 2);
+            std::memcpy(controlPoints.data(), ctrl.data() + (size_t)b * (K + 2) * 3, sizeof(double) * 3 * (K + 2));
+            planners[grp[b]]->installControlPoints(controlPoints, fitPts[grp[b]]);
+            ok[grp[b]] = true;
+        }
+    }
+    return ok;
 }
 
 void bsplineTraj::updateDynamicObstacles(const std::vector<Eigen::Vector3d>& obstaclesPos, const std::vector<Eigen::Vector3d>& obstaclesVel,

@@ -127,9 +127,27 @@ int main() {
             b->setMap(map);
             b->updateMaxVel(2.0);
             b->updateMaxAcc(3.0);
-            const double y = -2.4 + 0.1 * i;   // some hit the pillar, some pass beside it
-            b->updatePath(straight(-3.0, y, 3.0, y + 0.03, 1.0, 0.25), cond);
             ps.push_back(b);
+        }
+        // updatePathBatch: one device least-squares fit for all planners; planner 0 also runs the
+        // single-path host fit for comparison
+        std::vector<nav_msgs::Path> paths;
+        for (int i = 0; i < 48; ++i) {
+            const double y = -2.4 + 0.1 * i;   // some hit the pillar, some pass beside it
+            paths.push_back(straight(-3.0, y, 3.0, y + 0.03, 1.0, 0.25));
+        }
+        std::vector<bool> up = bsplineTraj::updatePathBatch(ps, paths, std::vector<std::vector<Eigen::Vector3d>>(48, cond));
+        int accepted = 0;
+        for (bool u : up) accepted += u;
+        CHECK(accepted == 48, "updatePathBatch accepts all 48 paths");
+        {
+            bsplineTraj single(makeParams());
+            single.setMap(map);
+            single.updatePath(paths[5], cond);
+            Eigen::MatrixXd a = single.getControlPoints(), d = ps[5]->getControlPoints();
+            double worst = 0;
+            for (int c = 0; c < a.cols(); ++c) for (int r = 0; r < 3; ++r) worst = std::fmax(worst, std::fabs(a(r, c) - d(r, c)));
+            CHECK(a.cols() == d.cols() && worst < 1e-10, "device batch fit == host single-path fit (1e-10)");
         }
         std::vector<bool> res = bsplineTraj::makePlanBatch(ps);
         int good = 0, clean = 0;

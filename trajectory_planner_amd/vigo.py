@@ -225,7 +225,17 @@ class Vigo:
                                             C.c_void_p(out.evals.data_ptr())), "vigo_optimize")
         return out
 
-    # ---- spline evaluation and gates ----------------------------------------------------
+    # ---- spline fit, evaluation and gates -----------------------------------------------
+    def bspline_fit(self, points, conds=None, ts=None):
+        """bspline::parameterizeToBspline for a batch: points [B,K,3] (+ conds [B,4,3]) -> ctrl [B,K+2,3]"""
+        B, K, _ = points.shape
+        ts = float(self.params.ts_ctrl if ts is None else ts)
+        out = torch.empty(B, K + 2, 3, dtype=torch.float64, device=self.device)
+        self._check(self._lib.vigo_bspline_fit(self._h, B, K, ts, _ptr(points, torch.float64, "points", self.device),
+                                               _ptr(conds, torch.float64, "conds", self.device),
+                                               C.c_void_p(out.data_ptr())), "vigo_bspline_fit")
+        return out
+
     def bspline_eval(self, ctrl, times, deriv=0):
         B, N, _ = ctrl.shape
         T = times.numel()
