@@ -29,6 +29,8 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kMaxMem = VIGO_MAX_MEM_SIZE;
+constexpr int kObsCache = 16;  // dynamic obstacles per trajectory staged in LDS by the solve kernel
+constexpr int kObsRec = 6;     // doubles per staged obstacle (5 used, 48-byte records)
 
 // reference status codes, LB:20-80
 enum : int {
@@ -209,6 +211,11 @@ struct LaneProblem {
     bool gqu[kGuideDim];
     int o_begin, o_end;       // this trajectory's obstacles
     const double* obs;
+    // (whole-solve kernel) the first kObsCache obstacles of this trajectory as {pos.x, pos.y,
+    // vel.x, vel.y, size} records in LDS, staged once per solve: they never change, and a global
+    // load per obstacle per evaluation is a ~2 us round trip on the critical path
+    const double* obs_cache;
+    int o_cached;
     double w[4];
 };
 
@@ -243,6 +250,34 @@ __device__ __forceinline__ void guide_pair_term(const DevConst& K, const T (&c)[
     if (!K.plan_in_z) gz = T(0.0);
     cd += (double)ct;
     Gd[0] += gx; Gd[1] += gy; Gd[2] += gz;
+}
+
+// One dynamic obstacle's contribution to one control point, BT.cpp:1011-1059: the obstacle at its
+// predicted positions n = 0, 2, .., predictionNum (skipFactor = 2, BT.cpp:1006).
+template <typename T>
+__device__ __forceinline__ void obstacle_term(const DevConst& K, const T (&c)[3], T opx, T opy, T ovx, T ovy, T size,
+                                              double& co, T (&Go)[3]) {
+    const T thr0 = (T)K.thr_dyn, oa = (T)K.oa, ob = (T)K.ob, oc = (T)K.oc;
+    for (int n = 0; n <= K.pred_num; n += 2) {
+        const T tn = (T)((double)n * K.ts);
+        const T px = opx + tn * ovx, py = opy + tn * ovy;
+        // integer division n/predictionNum, BT.cpp:1020
+        const T thr = (T(1) - (T)(n / K.pred_num) * T(0.2)) * thr0;
+        const T dx = c[0] - px, dy = c[1] - py, dz = T(0.0);
+        const T nrm = sqrt((dx * dx + dy * dy) + dz * dz);
+        const T e = thr - (nrm - size);
+        // BT.cpp:1030-1058: e <= 0 no punishment; 0 < e <= thr cubic; e >= thr quadratic.  The two
+        // penalty branches share their tail — grad = diff / |diff| (BT.cpp:1025) and the
+        // accumulation — so a wave whose lanes split between them pays the three fp64 divisions
+        // once, and a far step pays none.
+        if (e > T(0)) {
+            const bool cubic = e <= thr;
+            const T ct = cubic ? (e * e) * e : (oa * (e * e) + ob * e) + oc;
+            const T k = cubic ? T(-3.0) * (e * e) : -((T(2) * oa) * e + ob);
+            co += (double)ct;
+            Go[0] += k * (dx / nrm); Go[1] += k * (dy / nrm); Go[2] += k * (dz / nrm);
+        }
+    }
 }
 
 // ---- cost + gradient at the points held in c (BT.cpp:802-821) ---------------------------
@@ -389,38 +424,20 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
 
     // ---- dynamic obstacles, BT.cpp:1001-1064 ----
     if (Q.o_end > Q.o_begin) {
-        const T thr0 = (T)K.thr_dyn, oa = (T)K.oa, ob = (T)K.ob, oc = (T)K.oc;
 #pragma unroll
         for (int q = 0; q < PPL; ++q) {
             if (!Q.interior[q]) continue;
             double co = 0.0;
-            for (int j = Q.o_begin; j < Q.o_end; ++j) {
+            // the obstacles staged in LDS by the solve kernel first (same order as the list) ...
+            for (int j = 0; j < Q.o_cached; ++j) {
+                const double* oc = Q.obs_cache + kObsRec * j;
+                obstacle_term<T>(K, c[q], (T)oc[0], (T)oc[1], (T)oc[2], (T)oc[3], (T)oc[4], co, Go[q]);
+            }
+            // ... then the rest (all of them for the standalone cost/gradient kernel) from HBM/L2
+            for (int j = Q.o_begin + Q.o_cached; j < Q.o_end; ++j) {
                 const double* o = Q.obs + 9 * (size_t)j;
-                const T opx = (T)o[0], opy = (T)o[1], ovx = (T)o[3], ovy = (T)o[4];
                 const T hx = (T)o[6] / 2, hy = (T)o[7] / 2;
-                const T size = sqrt(hx * hx + hy * hy);
-                for (int n = 0; n <= K.pred_num; n += 2) {  // skipFactor = 2, BT.cpp:1006
-                    const T tn = (T)((double)n * K.ts);
-                    const T px = opx + tn * ovx, py = opy + tn * ovy;
-                    // integer division n/predictionNum, BT.cpp:1020
-                    const T thr = (T(1) - (T)(n / K.pred_num) * T(0.2)) * thr0;
-                    const T dx = c[q][0] - px, dy = c[q][1] - py, dz = T(0.0);
-                    const T nrm = sqrt((dx * dx + dy * dy) + dz * dz);
-                    const T e = thr - (nrm - size);
-                    // grad = diff / |diff| (BT.cpp:1025) is only consumed by the two penalty
-                    // branches: the three fp64 divisions are issued there, not for every far step
-                    if (e <= T(0)) {
-                        // no punishment
-                    } else if (e > T(0) && e <= thr) {
-                        co += (double)((e * e) * e);
-                        const T k = T(-3.0) * (e * e);
-                        Go[q][0] += k * (dx / nrm); Go[q][1] += k * (dy / nrm); Go[q][2] += k * (dz / nrm);
-                    } else if (e >= thr) {
-                        co += (double)((oa * (e * e) + ob * e) + oc);
-                        const T k = -((T(2) * oa) * e + ob);
-                        Go[q][0] += k * (dx / nrm); Go[q][1] += k * (dy / nrm); Go[q][2] += k * (dz / nrm);
-                    }
-                }
+                obstacle_term<T>(K, c[q], (T)o[0], (T)o[1], (T)o[3], (T)o[4], sqrt(hx * hx + hy * hy), co, Go[q]);
             }
             pt_o[q] = co;
         }
@@ -485,6 +502,8 @@ __device__ __forceinline__ void load_problem(const SolveArgs& A, const DevConst&
         }
     }
     Q.obs = A.obs;
+    Q.obs_cache = nullptr;
+    Q.o_cached = 0;
     if (A.obs_off) {
         Q.o_begin = A.obs_off[b];
         Q.o_end = A.obs_off[b + 1];
@@ -684,8 +703,13 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
     const int N = A.N, NI = N - 6;
     const int ROW = TPB * NI;
     const int m = K.mem_size;
+    // REG1 (one control point per lane): the two newest history pairs (ages 0 and 1) stay in
+    // registers, LDS holds the older m - 2 — at N = 64, m = 16 that is 38.3 KB instead of 43.8 KB
+    // per wave, i.e. four resident waves per CU (one per SIMD) instead of three.
+    constexpr bool REG1 = (PPL == 1);
+    const int ms = REG1 ? (m > 2 ? m - 2 : 0) : m;   // history slots in LDS
     HPair<T>* hist = reinterpret_cast<HPair<T>*>(lds_raw);
-    double* ys_tab = reinterpret_cast<double*>(lds_raw + (((size_t)m * ROW * sizeof(HPair<T>) + 15) & ~(size_t)15));
+    double* ys_tab = reinterpret_cast<double*>(lds_raw + (((size_t)ms * ROW * sizeof(HPair<T>) + 15) & ~(size_t)15));
 
     const int lane = threadIdx.x;
     const int grp = lane / GROUP;
@@ -705,6 +729,23 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
     }
     double* ys_l = ys_tab + grp;
     double* al_l = ys_tab + (size_t)m * TPB + grp;
+    if (A.obs) {
+        // stage this trajectory's obstacles (BT.cpp:1011-1015 operands) once; size in T arithmetic
+        double* oc = ys_tab + 2 * (size_t)m * TPB + (size_t)grp * kObsCache * kObsRec;
+        const int cnt = Q.o_end - Q.o_begin;
+        Q.o_cached = cnt < kObsCache ? cnt : kObsCache;
+        Q.obs_cache = oc;
+        for (int j = lane % GROUP; j < Q.o_cached; j += GROUP) {
+            const double* o = A.obs + 9 * (size_t)(Q.o_begin + j);
+            const T hx = (T)o[6] / 2, hy = (T)o[7] / 2;
+            oc[kObsRec * j + 0] = (double)(T)o[0];
+            oc[kObsRec * j + 1] = (double)(T)o[1];
+            oc[kObsRec * j + 2] = (double)(T)o[3];
+            oc[kObsRec * j + 3] = (double)(T)o[4];
+            oc[kObsRec * j + 4] = (double)(T)sqrt(hx * hx + hy * hy);
+        }
+        __syncthreads();  // one wave per workgroup: orders the staging writes before the lanes' reads
+    }
 
     // x holds this lane's control points: free variables where interior, fixed boundary points
     // elsewhere (their g, d, s, y are identically zero so they never move).
@@ -714,10 +755,16 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
     for (int q = 0; q < PPL; ++q)
 #pragma unroll
         for (int a = 0; a < 3; ++a) g[q][a] = xp[q][a] = gp[q][a] = d[q][a] = T(0);
+    T s1[PPL][3], y1[PPL][3];   // REG1: the age-1 pair of the next two-loop
+    double ys1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) s1[q][a] = y1[q][a] = T(0);
     double sums[7];
     int evals = 0;
     int ret = LBERR_UNKNOWN;
-    int k = 0, end = 0;
+    int k = 0, end = 0, last = 0;
     double fx = 0.0, step = 0.0;
     bool first = true;
 
@@ -846,7 +893,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
         for (int q = 0; q < PPL; ++q) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) { sv[q][a] = x[q][a] - xp[q][a]; yv[q][a] = g[q][a] - gp[q][a]; }
-            if (Q.interior[q]) {
+            if (!REG1 && Q.interior[q]) {
                 HPair<T> hp;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) { hp.s[a] = sv[q][a]; hp.y[a] = yv[q][a]; }
@@ -858,16 +905,18 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
         const double ys = ysyy[0], yy = ysyy[1];
         // the two-loop divides by ys of each pair (LB:1300, :1312); FAST keeps its reciprocal instead
         const double ys_div = FAST ? 1.0 / ys : ys;
-        ys_l[end * TPB] = ys_div;
+        if (!REG1) ys_l[end * TPB] = ys_div;
+        const bool have1 = REG1 && k >= 2;   // s1/y1 hold the previous iteration's pair (age 1 now)
 
         // two-loop recursion, LB:1286-1316, fully unrolled over the pair's age with a register
         // window of kWin pairs (static index age % kWin): the pair needed kWin steps ahead is
         // fetched from LDS into the window slot the current step has just consumed, so the
         // dependent chain never waits for LDS and does no address arithmetic or copies.
         const int bound = (m <= k) ? m : k;
+        // !REG1: slot of the pair just stored (age 0); REG1: slot of the age-2 pair (last one written)
+        const int newest = REG1 ? last : end;
+        if (!REG1) end = (end + 1 == m) ? 0 : end + 1;
         ++k;
-        const int newest = end;                        // slot of the pair just stored (age 0)
-        end = (end + 1 == m) ? 0 : end + 1;
 #pragma unroll
         for (int q = 0; q < PPL; ++q)
 #pragma unroll
@@ -877,8 +926,25 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
         T Ps[kWin][PPL][3], Py[kWin][PPL][3];
         double Pys[kWin];
         auto fetch = [&](int age, T (&s_)[PPL][3], T (&y_)[PPL][3], double& ys_) {
-            int slot = newest - age;
-            if (slot < 0) slot += m;
+            // (age is a literal after unrolling: the register cases fold away)
+            if (REG1 && age == 0) {
+#pragma unroll
+                for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { s_[q][a] = sv[q][a]; y_[q][a] = yv[q][a]; }
+                ys_ = ys_div;
+                return;
+            }
+            if (REG1 && age == 1) {
+#pragma unroll
+                for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { s_[q][a] = s1[q][a]; y_[q][a] = y1[q][a]; }
+                ys_ = ys1;
+                return;
+            }
+            int slot = REG1 ? newest - (age - 2) : newest - age;
+            if (slot < 0) slot += ms;
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
                 const HPair<T> h = hl[q][slot * ROW];
@@ -935,6 +1001,29 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
                 if (age - kWin >= 0) fetch(age - kWin, Ps[w], Py[w], Pys[w]);
             }
         }
+        if (REG1) {
+            // the age-1 pair turns age 2 for the next two-loop: it leaves the registers for the LDS
+            // ring (overwriting the pair that would be age m), the new pair takes its place
+            if (have1 && ms > 0) {
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) {
+                    if (Q.interior[q]) {
+                        HPair<T> hp;
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) { hp.s[a] = s1[q][a]; hp.y[a] = y1[q][a]; }
+                        hl[q][end * ROW] = hp;
+                    }
+                }
+                ys_l[end * TPB] = ys1;
+                last = end;
+                end = (end + 1 == ms) ? 0 : end + 1;
+            }
+#pragma unroll
+            for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { s1[q][a] = sv[q][a]; y1[q][a] = yv[q][a]; }
+            ys1 = ys_div;
+        }
         sums[4] = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(g, d));  // dginit of the next line search (LB:746)
         step = 1.0;  // LB:1321
     }
@@ -957,11 +1046,14 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
 }
 
 template <typename T, int GROUP>
-size_t optimize_lds_bytes(int N, int m) {
+size_t optimize_lds_bytes(int N, int m, int ppl, bool with_obstacles) {
     const int TPB = kWave / GROUP;
-    size_t h = (size_t)m * TPB * (N - 6) * sizeof(HPair<T>);
+    const int ms = ppl == 1 ? (m > 2 ? m - 2 : 0) : m;   // REG1: ages 0 and 1 live in registers
+    size_t h = (size_t)ms * TPB * (N - 6) * sizeof(HPair<T>);
     h = (h + 15) & ~(size_t)15;
-    return h + 2 * (size_t)m * TPB * sizeof(double);
+    h += 2 * (size_t)m * TPB * sizeof(double);
+    if (with_obstacles) h += (size_t)TPB * kObsCache * kObsRec * sizeof(double);
+    return h;
 }
 
 constexpr size_t kLdsPerWorkgroup = 160 * 1024;
@@ -1031,7 +1123,7 @@ int launch_cost_grad(hipStream_t s, const SolveArgs& a, const DevConst& k, const
 template <typename T, int GROUP, int PPL, bool FAST>
 static int launch_optimize_t(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd) {
     const int tpb = kWave / GROUP;
-    const size_t lds = optimize_lds_bytes<T, GROUP>(a.N, k.mem_size);
+    const size_t lds = optimize_lds_bytes<T, GROUP>(a.N, k.mem_size, PPL, a.obs != nullptr);
     if (lds > kLdsPerWorkgroup) return (int)hipErrorInvalidValue;  // refused earlier by vigo_optimize
     static bool attr_set = false;
     if (!attr_set) {
@@ -1068,8 +1160,9 @@ int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, const 
 // bytes of LDS one trajectory-solve workgroup needs; the C ABI refuses N it cannot hold
 size_t optimize_lds_requirement(int N, int mem_size, int precision) {
     const bool g32 = N <= 32;
-    if (precision == VIGO_PREC_F32) return g32 ? optimize_lds_bytes<float, 32>(N, mem_size) : optimize_lds_bytes<float, 64>(N, mem_size);
-    return g32 ? optimize_lds_bytes<double, 32>(N, mem_size) : optimize_lds_bytes<double, 64>(N, mem_size);
+    const int ppl = N <= 64 ? 1 : (N <= 128 ? 2 : 4);
+    if (precision == VIGO_PREC_F32) return g32 ? optimize_lds_bytes<float, 32>(N, mem_size, ppl, true) : optimize_lds_bytes<float, 64>(N, mem_size, ppl, true);
+    return g32 ? optimize_lds_bytes<double, 32>(N, mem_size, ppl, true) : optimize_lds_bytes<double, 64>(N, mem_size, ppl, true);
 }
 
 }  // namespace vigo
