@@ -47,6 +47,7 @@ def parse():
                     help="f64: reference expression order (default); f64_fast: explicit fma + reciprocal "
                          "two-loop (VIGO_PREC_F64_FAST, same 1e-4 parity gate); f32: fp32 state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and other-arithmetic-mode side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -212,6 +213,50 @@ def main():
         elapsed = float(te.item())
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+
+    # ---- side measurements (outside the timed region above; rank 0 of a single-GPU run only) ----
+    extra = {}
+    if rank == 0 and world_size == 1 and not args.no_extras:
+        k2 = max(10, args.steps // 4)
+        # (a) the boundary handing over HOST buffers: pinned H2D of control points + guide pairs,
+        #     solve, D2H of control points and status — the PCIe-inclusive rate (never `value`)
+        h_ctrl = torch.from_numpy(np.ascontiguousarray(batch.ctrl)).pin_memory()
+        h_gpv = torch.from_numpy(np.ascontiguousarray(batch.guide_pv)).pin_memory()
+        h_goff = torch.from_numpy(np.ascontiguousarray(batch.guide_off)).pin_memory()
+        h_out = torch.empty_like(h_ctrl).pin_memory()
+        h_st = torch.empty(B, dtype=torch.int32).pin_memory()
+
+        def host_step():
+            work.copy_(h_ctrl, non_blocking=True)
+            gpv.copy_(h_gpv, non_blocking=True)
+            goff.copy_(h_goff, non_blocking=True)
+            gunk = v.guides_unknown(gpv) if gpv.shape[0] else None
+            v.optimize(work, goff, gpv if gpv.shape[0] else None, gunk, inplace=True, out=res)
+            h_out.copy_(work, non_blocking=True)
+            h_st.copy_(res.status, non_blocking=True)
+            torch.cuda.synchronize()
+
+        for _ in range(3):
+            host_step()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            host_step()
+        dt = (time.perf_counter() - t1) / k2
+        extra["pcie_inclusive"] = {"value": B / dt, "unit": "trajectories/s", "ms_per_step": dt * 1e3,
+                                   "note": "pinned H2D of ctrl/guides + solve + D2H of ctrl/status, synchronous per batch"}
+        # (b) the other fp64 arithmetic mode on the same batch (same 1e-4 parity gate, tests/test_gpu_solver.py)
+        other = "f64_fast" if args.precision == "f64" else "f64"
+        v.set_precision({"f32": PREC_F32, "f64": PREC_F64, "f64_fast": 2}[other])
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / k2
+        extra["other_mode"] = {"arithmetic": other, "value": B / dt, "unit": "trajectories/s", "ms_per_step": dt * 1e3}
+        v.set_precision({"f32": PREC_F32, "f64": PREC_F64, "f64_fast": 2}[args.precision])
     iters = res.iters.cpu().numpy()
     evals = res.evals.cpu().numpy()
     gp = np.diff(batch.guide_off).reshape(B, N).sum(1)
@@ -258,6 +303,7 @@ def main():
                          "compulsory_bytes_per_launch": compulsory,
                          "compulsory_frac": compulsory / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        out.update(extra)
         if cpu is not None:
             out["cpu_baseline"] = {"value": cpu["single"], "unit": "trajectories/s", "cores": 1, "kind": "port",
                                    "sample": f"{cpu['single_n']} solves: repeats of the first 256 trajectories of the same "

@@ -31,14 +31,44 @@ def solve_cfg(name, world, B, N, prec, n_obs=0, reps=20):
         return v.optimize(ctrl, goff, gpv, gunk, ooff, obs)
     dt = timeit(step, reps)
     r = step()
-    print(json.dumps({"config": name, "B": B, "N": N, "precision": "f32" if prec == PREC_F32 else "f64", "obstacles_per_traj": n_obs,
+    print(json.dumps({"config": name, "B": B, "N": N, "precision": {PREC_F32: "f32", PREC_F64: "f64", 2: "f64_fast"}[prec], "obstacles_per_traj": n_obs,
                       "ms_per_batch": dt * 1e3, "trajs_per_s": B / dt, "mean_evals": float(r.evals.float().mean()),
                       "mean_iters": float(r.iters.float().mean())}), flush=True)
     v.close()
 
 
+# config 1: polyTrajOctomap::makePlan on the maze fixture (host QP + device box sweep), via the facade library
+import ctypes as C
+sys.path.insert(0, os.path.join(R, "tests"))
+try:
+    import test_gpu_config1 as c1
+    vox, origin, res, wp, _ = c1.load_maze()
+    cfg = [0.4, 0.4, 0.2, 0.2, 0.1, 1.0, 0.5, 0.8, 8.0, 100, 0.1, 0.0]
+    c1.plan(vox, origin, res, wp, cfg)
+    ts = []
+    for _ in range(10):
+        traj, info = c1.plan(vox, origin, res, wp, cfg)
+        ts.append(info[4])
+    print(json.dumps({"config": "1: polyTrajOctomap makePlan, maze.bt, 8 waypoints (host QP + device sweep)", "valid": bool(info[0]),
+                      "corridor_iterations": int(info[1]), "samples": int(info[2]), "makePlan_ms_median": float(np.median(ts)) * 1e3,
+                      "makePlan_ms_min": float(np.min(ts)) * 1e3}), flush=True)
+except Exception as e:  # noqa
+    print(json.dumps({"config": "1", "error": repr(e)}), flush=True)
+
+# B-spline fit (updatePath batched): config 2 and config 4 shapes
+v = Vigo(0)
+rng = np.random.default_rng(11)
+for (Bf, Kf) in ((1024, 30), (65536, 30), (8192, 62), (65536, 62)):
+    pts = T(rng.normal(size=(Bf, Kf, 3)))
+    v.bspline_fit(pts)
+    dt = timeit(lambda: v.bspline_fit(pts), 50)
+    print(json.dumps({"config": f"fit: {Bf} paths x {Kf} waypoints", "ms": dt * 1e3, "paths_per_s": Bf / dt,
+                      "algorithmic_GBps": Bf * (2 * Kf + 6) * 24 / dt / 1e9}), flush=True)
+v.close()
+
 w256 = synth.make_box_world(synth.SEED_BASE + 2, n=256, n_boxes=200)
 solve_cfg("2: 1024x32, 256^3, 50 it", w256, 1024, 32, PREC_F64)
+solve_cfg("2 (f64_fast mode)", w256, 1024, 32, 2)
 solve_cfg("2 (fp32 mode)", w256, 1024, 32, PREC_F32)
 solve_cfg("2 at B=16384", w256, 16384, 32, PREC_F64, reps=5)
 solve_cfg("5a: dynamic-obstacle term, 8 obstacles/traj", w256, 1024, 32, PREC_F64, n_obs=8)
@@ -84,3 +114,4 @@ v.close()
 # config 4 shard: 8192 x 64 control points, 512^3 grid
 w512 = synth.make_box_world(synth.SEED_BASE + 4, n=512, n_boxes=800, centre_range=24.0)
 solve_cfg("4 shard: 8192x64, 512^3, 50 it (one of 8 GPUs)", w512, 8192, 64, PREC_F64, reps=5)
+solve_cfg("4 shard (f64_fast mode)", w512, 8192, 64, 2, reps=5)
