@@ -241,7 +241,29 @@ int vigo_traj_dynamic_collision(vigo_handle_t h, int B, int N, const double* ctr
 int vigo_ctrl_occupancy(vigo_handle_t h, int B, int N, const double* ctrl,
                         uint8_t* out_pt, uint8_t* out_line);
 
-/* ---- min-snap corridor collision checker ------------------------------------------- */
+/* ---- min-snap QP and corridor collision checker ------------------------------------ */
+
+/*
+ * Replaces: polyTrajSolver::solve (PS.cpp:849-904) with constructP/constructA/constructBound
+ * (:241-846), avgTimeAllocation (:125-138), updateCorridorParam (:985-1012) and the rescale to
+ * un-normalised local time (:874-878) — the three per-axis QPs the reference hands to OSQP —
+ * for T waypoint paths of W waypoints (W-1 degree-7 segments) each, one wavefront per path,
+ * solved exactly (null-space elimination of the equality rows + dual active set on the corridor
+ * boxes) instead of ADMM to eps 1e-3.
+ *   waypoints  double[T][W][3]
+ *   corridor   double[T][W-1]  corridor half-size per segment (0 = no boxes there,
+ *                              PS.cpp:992); NULL = no corridor constraint (makePlanAddingWaypoint)
+ *   conds      double[T][4][3] init vel, end vel, init acc, end acc (PS.h updateInitVel/...); NULL = 0
+ *   out_coeffs double[T][W-1][3][deg+1]   == the `coeffs` layout of vigo_corridor_check (S = T*(W-1))
+ *   out_knots  double[T][W]    desiredTime_ (PS.cpp:125-138)
+ *   out_status int32[T]        0 solved, -1 numerical failure (coincident waypoints, > 1024 boxes),
+ *                              -2 infeasible corridor (the reference keeps a stale solution silently)
+ * deg must be 7; 2 <= W <= 11; diff/cont as polynomial/continuity degrees of cfg/planner*.yaml.
+ */
+int vigo_minsnap(vigo_handle_t h, int T, int W, int deg, int diff, int cont, double desired_vel,
+                 double corridor_res, const double* waypoints, const double* corridor,
+                 const double* conds, double* out_coeffs, double* out_knots, int32_t* out_status);
+
 
 /*
  * Replaces: polyTrajOctomap::checkCollisionTraj (PO.cpp:634-656) -> checkCollision

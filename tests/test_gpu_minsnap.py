@@ -1,0 +1,164 @@
+"""-m gpu: batched min-snap QP on the device (vigo_minsnap = polyTrajSolver::solve, PS.cpp:849-904 with
+its problem construction).  Checked (a) against the closed-form KKT solution of the equality-constrained
+case in numpy, (b) by algorithm-independent KKT conditions (non-negative multipliers on the active
+corridor boxes) for the corridor case, (c) against the host restatement of the same algorithm in
+libtrajectory_planner_vigo.so, on the reference's literal test waypoints (src/test/waypoint.yaml), the
+maze waypoints of BASELINE configs[0] and random paths.  Parity unpinned by reference data: the reference
+delegates to OSQP (prebuilt third-party binaries, never loaded) and stops at eps 1e-3; tolerances below
+are on the exact optimum (1e-6 relative on the trajectory), tighter than OSQP's own."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import to_dev
+from minsnap_ref import corridor_rows, evaluate, kkt_violation, minsnap_matrices
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIX = np.load(os.path.join(ROOT, "tests", "golden", "fixtures.npz"))
+MAZE = np.load(os.path.join(ROOT, "tests", "golden", "maze_config1.npz"))
+HOSTLIB = os.path.join(ROOT, "trajectory_planner_amd", "lib", "libtrajectory_planner_vigo.so")
+_dp = C.POINTER(C.c_double)
+
+
+def host_solve(wp, corridor=None, cres=8.0):
+    L = C.CDLL(HOSTLIB)
+    L.vigo_host_minsnap.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_double, _dp, _dp]
+    K = len(wp) - 1
+    co, kn = np.zeros((3, K * 8)), np.zeros(len(wp))
+    w = np.ascontiguousarray(wp, dtype=np.float64)
+    cor = None if corridor is None else np.ascontiguousarray(corridor, dtype=np.float64)
+    rc = L.vigo_host_minsnap(len(wp), w.ctypes.data_as(_dp), 7, 4, 4, 1.0, None if cor is None else cor.ctypes.data_as(_dp), cres,
+                             co.ctypes.data_as(_dp), kn.ctypes.data_as(_dp))
+    return rc, co, kn
+
+
+def dev_to_axis_major(coeffs):
+    """[K,3,8] -> [3, K*8] (the host / numpy layout)"""
+    return np.ascontiguousarray(np.transpose(coeffs, (1, 0, 2)).reshape(3, -1))
+
+
+def random_paths(rng, T, W):
+    wp = np.zeros((T, W, 3))
+    wp[:, 0] = rng.uniform(-5, 5, size=(T, 3)) * [1, 1, 0.2] + [0, 0, 1]
+    for i in range(1, W):
+        step = rng.normal(size=(T, 3)) * [1, 1, 0.15]
+        step *= (rng.uniform(1.0, 3.5, size=(T, 1)) / np.linalg.norm(step, axis=1, keepdims=True))
+        wp[:, i] = wp[:, i - 1] + step
+    return wp
+
+
+@pytest.mark.parametrize("W", [2, 3, 4, 8, 11])
+def test_equality_constrained_matches_the_kkt_closed_form(vigo_handle, W):
+    v = vigo_handle
+    rng = np.random.default_rng(W)
+    T = 9
+    wp = random_paths(rng, T, W)
+    if W == 4:
+        wp[0] = FIX["waypoints"]                                     # src/test/waypoint.yaml
+    if W == 8:
+        wp[0] = MAZE["waypoints"]
+    coeffs, knots, status = (x.cpu().numpy() for x in v.minsnap(to_dev(wp, v.device)))
+    assert (status == 0).all()
+    for t in range(T):
+        P, A, b, Tk = minsnap_matrices(wp[t], 7, 4, 4, 1.0)
+        assert np.allclose(knots[t], Tk, rtol=1e-14, atol=0)
+        n, m = P.shape[0], A.shape[0]
+        KKT = np.block([[P, A.T], [A, np.zeros((m, m))]])
+        c = dev_to_axis_major(coeffs[t])
+        scale = np.concatenate([(Tk[s + 1] - Tk[s]) ** np.arange(8) for s in range(W - 1)])
+        for a in range(3):
+            sol = np.linalg.lstsq(KKT, np.concatenate([np.zeros(n), b[:, a]]), rcond=None)[0][:n]
+            x = c[a] * scale
+            # (continuity rows carry dt^order factors: residual relative to the row's own scale)
+            assert (np.abs(A @ x - b[:, a]) / np.abs(A).max(axis=1)).max() < 1e-10
+            assert abs(x @ P @ x - sol @ P @ sol) <= 1e-7 * max(1.0, sol @ P @ sol)
+            for tt in np.linspace(0, Tk[-1], 25):
+                i = max(min(np.searchsorted(Tk, tt, side="right") - 1, W - 2), 0)
+                pk = (sol[i * 8:(i + 1) * 8] / (Tk[i + 1] - Tk[i]) ** np.arange(8)) @ ((tt - Tk[i]) ** np.arange(8))
+                assert abs(evaluate(c, Tk, tt)[a] - pk) < 1e-6 * max(1.0, abs(pk))
+
+
+def test_corridor_case_satisfies_kkt_and_matches_the_host_solver(vigo_handle):
+    v = vigo_handle
+    rng = np.random.default_rng(17)
+    wp = random_paths(rng, 12, 8)
+    wp[0] = MAZE["waypoints"]
+    wp[1, :4] = FIX["waypoints"]
+    cor = np.full((12, 7), 0.5)
+    cor[2:] = rng.uniform(0.3, 0.8, size=(10, 7))
+    cor[3, 2] = 0.0                                                     # a segment without boxes (PS.cpp:992)
+    coeffs, knots, status = (x.cpu().numpy() for x in v.minsnap(to_dev(wp, v.device), to_dev(cor, v.device)))
+    solved = 0
+    for t in range(12):
+        rc, hco, hkn = host_solve(wp[t], cor[t])
+        assert (rc == 0) == (status[t] == 0), (t, rc, status[t])
+        if status[t] != 0:
+            assert status[t] == -2
+            continue
+        solved += 1
+        c = dev_to_axis_major(coeffs[t])
+        P, Aeq, beq, Tk = minsnap_matrices(wp[t], 7, 4, 4, 1.0)
+        Cm, cen, rad = corridor_rows(wp[t], Tk, cor[t], 8.0)
+        scale = np.concatenate([(Tk[s + 1] - Tk[s]) ** np.arange(8) for s in range(7)])
+        for a in range(3):
+            prim, stat = kkt_violation(P, Aeq, beq[:, a], Cm, cen[:, a] - rad, cen[:, a] + rad, c[a] * scale)
+            assert prim < 1e-7 and stat < 1e-6, (t, a, prim, stat)
+        for tt in np.linspace(0, Tk[-1], 40):
+            assert np.allclose(evaluate(c, Tk, tt), evaluate(hco, hkn, tt), rtol=1e-7, atol=1e-7)
+    assert solved >= 6
+
+
+def test_infeasible_corridor_and_degenerate_paths_are_reported(vigo_handle):
+    v = vigo_handle
+    wp = np.array([[[0, 0, 1], [2, 0.2, 1], [3, 2.5, 1.2], [5.5, 3, 1]]], dtype=float)
+    _, _, status = v.minsnap(to_dev(wp, v.device), to_dev(np.full((1, 3), 0.08), v.device))
+    assert status.cpu().numpy()[0] == -2                              # same case as tests/test_host_plumbing.py
+    dup = wp.copy()
+    dup[0, 2] = dup[0, 1]                                             # coincident waypoints: a zero-length segment
+    _, _, status = v.minsnap(to_dev(dup, v.device))
+    assert status.cpu().numpy()[0] in (0, -1)                         # reported or solved, never a hang / NaN status
+    from trajectory_planner_amd.vigo import VigoError
+    with pytest.raises(VigoError):
+        v.minsnap(torch.zeros(1, 12, 3, dtype=torch.float64, device=v.device))
+    with pytest.raises(VigoError):
+        v.minsnap(torch.zeros(1, 4, 3, dtype=torch.float64, device=v.device), deg=5)
+    c, k, s = v.minsnap(torch.zeros(0, 4, 3, dtype=torch.float64, device=v.device))
+    assert c.shape == (0, 3, 3, 8)
+
+
+def test_minsnap_to_corridor_checker_pipeline_at_config3_size(vigo_handle):
+    """BASELINE configs[2] with real coefficients: 586 paths x 7 segments = 4102 min-snap segments straight
+    into vigo_corridor_check (same coefficient layout); property checks only (the checker has its own parity
+    tests): interpolation of the waypoints, determinism, and agreement of the first path with the maze plan"""
+    v = vigo_handle
+    rng = np.random.default_rng(5)
+    T = 586
+    wp = random_paths(rng, T, 8)
+    wp[0] = MAZE["waypoints"]
+    cor = np.full((T, 7), 0.5)
+    d_wp, d_cor = to_dev(wp, v.device), to_dev(cor, v.device)
+    coeffs, knots, status = v.minsnap(d_wp, d_cor)
+    c2, k2, s2 = v.minsnap(d_wp, d_cor)
+    assert torch.equal(coeffs, c2) and torch.equal(status, s2)
+    st = status.cpu().numpy()
+    assert (st == 0).sum() >= T // 2 and set(np.unique(st)) <= {0, -2}
+    co, kn = coeffs.cpu().numpy(), knots.cpu().numpy()
+    ok = np.where(st == 0)[0]
+    start = co[ok][:, :, :, 0]                                         # value at local time 0 = the segment's first waypoint
+    assert np.abs(start - wp[ok][:, :-1]).max() < 1e-7
+    # the maze path: corridor 0.5 is collision free (tests/test_gpu_config1.py plans the same path on the host)
+    nx, ny, nz = (int(x) for x in MAZE["dims"])
+    nvox = nx * ny * nz
+    occ = np.unpackbits(MAZE["occ_bits"])[:nvox].reshape(nx, ny, nz)
+    unk = np.unpackbits(MAZE["unk_bits"])[:nvox].reshape(nx, ny, nz)
+    v.set_grid(to_dev((occ * 5 + unk * 2).astype(np.uint8), v.device), MAZE["origin"], float(MAZE["res"][0]))
+    dur = np.diff(kn, axis=1).reshape(-1)
+    n_samp = np.full(T * 7, 1000, dtype=np.int32)
+    delT = dur / 1000.0
+    seg_coeffs = coeffs.reshape(T * 7, 3, 8)
+    flag, first, count = v.corridor_check(seg_coeffs, to_dev(n_samp, v.device), to_dev(delT, v.device), [0.4, 0.4, 0.2], 0.2)
+    assert st[0] == 0 and not flag.cpu().numpy()[:7].any()

@@ -9,6 +9,8 @@ import struct
 import numpy as np
 import pytest
 
+from minsnap_ref import corridor_rows, evaluate, kkt_violation, minsnap_matrices
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "trajectory_planner_amd", "lib", "libtrajectory_planner_vigo.so")
 _dp = C.POINTER(C.c_double)
@@ -161,60 +163,6 @@ def test_maze_fixture_is_the_parsed_reference_tree(host):
 
 
 # ---- min-snap QP
-def minsnap_matrices(wp, deg, diff, cont, vel):
-    """numpy statement of the QP (normalised time) for the equality-constrained case"""
-    K = len(wp) - 1
-    D = deg + 1
-    T = np.concatenate([[0], np.cumsum(np.linalg.norm(np.diff(wp, axis=0), axis=1) / vel)])
-    n = K * D
-    P = np.zeros((n, n))
-    for s in range(K):
-        for i in range(diff, D):
-            for j in range(diff, D):
-                f = 1.0
-                for d in range(diff):
-                    f *= (i - d) * (j - d)
-                P[s * D + i, s * D + j] = f / (i + j - 2 * diff + 1)
-
-    def dv(d, order, t):
-        if d < order:
-            return 0.0
-        f = 1.0
-        for k in range(order):
-            f *= d - k
-        return f * t ** (d - order)
-
-    rows, rhs = [], []
-
-    def row(entries, b):
-        r = np.zeros(n)
-        for c, v in entries:
-            r[c] += v
-        rows.append(r)
-        rhs.append(b)
-
-    last = (K - 1) * D
-    row([(d, dv(d, 0, 0.0)) for d in range(D)], wp[0])
-    row([(last + d, dv(d, 0, 1.0)) for d in range(D)], wp[-1])
-    for i in range(K - 1):
-        row([(i * D + d, dv(d, 0, 1.0)) for d in range(D)], wp[i + 1])
-    for i in range(K - 1):
-        row([(i * D + d, dv(d, 0, 1.0)) for d in range(D)] + [((i + 1) * D + d, -dv(d, 0, 0.0)) for d in range(D)], np.zeros(3))
-    for order in (1, 2):
-        row([(d, dv(d, order, 0.0)) for d in range(D)], np.zeros(3))
-        row([(last + d, dv(d, order, 1.0)) for d in range(D)], np.zeros(3))
-        for i in range(K - 1):
-            dl, dr = T[i + 1] - T[i], T[i + 2] - T[i + 1]
-            row([(i * D + d, dv(d, order, 1.0) * dr ** order) for d in range(D)] +
-                [((i + 1) * D + d, -dv(d, order, 0.0) * dl ** order) for d in range(D)], np.zeros(3))
-    for order in range(3, cont + 1):
-        for i in range(K - 1):
-            dl, dr = T[i + 1] - T[i], T[i + 2] - T[i + 1]
-            row([(i * D + d, dv(d, order, 1.0) * dr ** order) for d in range(D)] +
-                [((i + 1) * D + d, -dv(d, order, 0.0) * dl ** order) for d in range(D)], np.zeros(3))
-    return P, np.array(rows), np.array(rhs), T
-
-
 def solve_c(host, wp, deg=7, diff=4, cont=4, vel=1.0, corridor=None, cres=8.0):
     K = len(wp) - 1
     coeffs = np.zeros((3, K * (deg + 1)))
@@ -226,14 +174,6 @@ def solve_c(host, wp, deg=7, diff=4, cont=4, vel=1.0, corridor=None, cres=8.0):
                                 knots.ctypes.data_as(_dp))
     assert rc == 0
     return coeffs, knots
-
-
-def evaluate(coeffs, knots, t, deg=7):
-    i = min(np.searchsorted(knots, t, side="right") - 1, len(knots) - 2)
-    i = max(i, 0)
-    lt = t - knots[i]
-    c = coeffs[:, i * (deg + 1):(i + 1) * (deg + 1)]
-    return c @ (lt ** np.arange(deg + 1))
 
 
 def test_minsnap_matches_the_kkt_solution_on_the_reference_waypoints(host):
@@ -294,6 +234,15 @@ def test_minsnap_corridor_constraints_hold_and_tighten(host):
         objs.append(sum(0.5 * (c[a] * scale) @ P @ (c[a] * scale) for a in range(3)))
     assert all(objs[i + 1] >= objs[i] * (1 - 1e-3) for i in range(3)), objs
     assert objs[3] > objs[0] * 1.01, objs
+    # algorithm-independent optimality: KKT conditions with sign-feasible multipliers on the active boxes
+    for r in (0.5, 0.3, 0.2):
+        c, k = solve_c(host, wp, corridor=[r] * 3, cres=8.0)
+        P, Aeq, beq, T = minsnap_matrices(wp, 7, 4, 4, 1.0)
+        Cm, cen, rad = corridor_rows(wp, T, [r] * 3, 8.0)
+        scale = np.concatenate([(T[s + 1] - T[s]) ** np.arange(8) for s in range(3)])
+        for a in range(3):
+            prim, stat = kkt_violation(P, Aeq, beq[:, a], Cm, cen[:, a] - rad, cen[:, a] + rad, c[a] * scale)
+            assert prim < 1e-7 and stat < 1e-6, (r, a, prim, stat)
     # an infeasible corridor (8 cm around corners at 1 m/s with C4 continuity) is reported, not hidden
     K = len(wp) - 1
     co, kn, cor = np.zeros((3, K * 8)), np.zeros(len(wp)), np.full(K, 0.08)

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "vigo_traj_collision": (_i, [_vp, _i, _i, _vp, _d, _vp, _vp]),
     "vigo_traj_dynamic_collision": (_i, [_vp, _i, _i, _vp, _d, _vp, _vp, _i, _vp]),
     "vigo_ctrl_occupancy": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "vigo_minsnap": (_i, [_vp, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vigo_corridor_check": (_i, [_vp, _i, _i, _vp, _vp, _vp, _d3, _d, _vp, _vp, _vp]),
     "vigo_box_collision_points": (_i, [_vp, _i64, _vp, _d3, _d, _vp]),
     "vigo_accumulated_time": (_d, [_d, _i64]),

@@ -394,7 +394,25 @@ int vigo_ctrl_occupancy(vigo_handle_t h, int B, int N, const double* ctrl, uint8
     return VIGO_OK;
 }
 
-/* ---- corridor checker ------------------------------------------------------------------- */
+/* ---- min-snap QP and corridor checker ---------------------------------------------------- */
+
+int vigo_minsnap(vigo_handle_t h, int T, int W, int deg, int diff, int cont, double desired_vel, double corridor_res,
+                 const double* waypoints, const double* corridor, const double* conds, double* out_coeffs,
+                 double* out_knots, int32_t* out_status) {
+    if (!h) return VIGO_ERR_INVALID_ARG;
+    if (T < 0 || !(desired_vel > 0) || (corridor && !(corridor_res > 0)) || (T > 0 && (!waypoints || !out_coeffs || !out_knots || !out_status)))
+        return fail(h, VIGO_ERR_INVALID_ARG, "vigo_minsnap: bad argument");
+    if (deg != 7 || diff < 1 || diff > deg) return fail(h, VIGO_ERR_UNSUPPORTED, "vigo_minsnap: degree 7 polynomials only (polynomial_degree of cfg/planner*.yaml)");
+    if (W < 2 || W > vigo::minsnap_max_waypoints()) return fail(h, VIGO_ERR_UNSUPPORTED_N, "vigo_minsnap: 2..11 waypoints per path on the device");
+    const int K = W - 1;
+    const int me = (2 + (K - 1) + (K - 1)) + 2 * (2 + (K - 1)) + (K - 1) * (cont - 2);
+    if (cont < 2 || me > 64 || me > K * 8 || K * 8 - me > 40 || vigo::minsnap_lds_bytes(W, cont) > (size_t)160 * 1024)
+        return fail(h, VIGO_ERR_UNSUPPORTED, "vigo_minsnap: continuity degree outside what one wavefront / 160 KiB of LDS holds");
+    VIGO_HIP(h, (hipError_t)vigo::launch_minsnap(h->stream, T, W, deg, diff, cont, desired_vel, corridor_res, waypoints, corridor, conds,
+                                                 out_coeffs, out_knots, out_status));
+    return VIGO_OK;
+}
+
 
 int vigo_corridor_check(vigo_handle_t h, int S, int deg, const double* coeffs, const int32_t* n_samp,
                         const double* delT, const double box[3], double map_res, uint8_t* out_flag,

@@ -108,6 +108,13 @@ int launch_fit_setup(hipStream_t s, int K, double ts, double* work, double* pinv
 int launch_bspline_fit(hipStream_t s, int B, int K, const double* pinvT, const double* points,
                        const double* conds, double* out);
 
+// batched min-snap QP (vigo_minsnap.hip)
+size_t minsnap_lds_bytes(int W, int cont);
+int minsnap_max_waypoints();
+int launch_minsnap(hipStream_t s, int T, int W, int deg, int diff, int cont, double vel, double corridor_res,
+                   const double* wp, const double* corridor, const double* conds, double* out_coeffs,
+                   double* out_knots, int32_t* out_status);
+
 }  // namespace vigo
 
 struct vigo_context {

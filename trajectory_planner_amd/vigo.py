@@ -274,6 +274,21 @@ class Vigo:
         return pt, line
 
     # ---- corridor checker ---------------------------------------------------------------
+    def minsnap(self, waypoints, corridor=None, conds=None, deg=7, diff=4, cont=4, vel=1.0, corridor_res=8.0):
+        """polyTrajSolver::solve for a batch of paths: waypoints [T,W,3] (+ corridor [T,W-1], conds [T,4,3])
+        -> (coeffs [T,W-1,3,deg+1], knots [T,W], status [T])"""
+        T, W, _ = waypoints.shape
+        coeffs = torch.zeros(T, W - 1, 3, deg + 1, dtype=torch.float64, device=self.device)
+        knots = torch.zeros(T, W, dtype=torch.float64, device=self.device)
+        status = torch.full((T,), -99, dtype=torch.int32, device=self.device)
+        self._check(self._lib.vigo_minsnap(self._h, T, W, deg, diff, cont, float(vel), float(corridor_res),
+                                           _ptr(waypoints, torch.float64, "waypoints", self.device),
+                                           _ptr(corridor, torch.float64, "corridor", self.device),
+                                           _ptr(conds, torch.float64, "conds", self.device),
+                                           C.c_void_p(coeffs.data_ptr()), C.c_void_p(knots.data_ptr()),
+                                           C.c_void_p(status.data_ptr())), "vigo_minsnap")
+        return coeffs, knots, status
+
     def corridor_check(self, coeffs, n_samp, delT, box, map_res):
         """coeffs [S,3,deg+1] f64, n_samp [S] i32, delT [S] f64 -> (flag u8[S], first i32[S], count i32[S])."""
         S, three, d1 = coeffs.shape
