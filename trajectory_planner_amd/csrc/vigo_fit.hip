@@ -12,15 +12,18 @@
 //                 (rows) read consecutive addresses;
 //   k_bspline_fit one wave per workgroup, lane <-> control point (row of A+): the lane keeps its
 //                 row of A+ in registers for all trajectories of its grid-stride loop, the K+4
-//                 input rows of a trajectory are staged through LDS (coalesced HBM read, broadcast
-//                 LDS reads), output [K+2][3] written coalesced.  HBM-bound:
+//                 input rows of a trajectory arrive through the scalar cache (wave-uniform
+//                 addresses), output [K+2][3] written coalesced.  HBM-bound:
 //                 (2K + 6) * 24 algorithmic bytes per trajectory.
-// fp64, -ffp-contract=off, sums in index order: deterministic, batch-invariant.
+// fp64, explicit fused multiply-adds in index order: deterministic, batch-invariant.
 #include "vigo_internal.hpp"
 
 namespace vigo {
 namespace {
 
+#ifndef VIGO_FIT_LDS_STORE
+#define VIGO_FIT_LDS_STORE 1
+#endif
 constexpr int kSetupThreads = 256;
 constexpr int kMaxRows = VIGO_MAX_CTRL_POINTS + 2;  // R = K + 4 <= N_max + 2
 
@@ -107,34 +110,78 @@ __device__ __forceinline__ double fit_rhs(const double* __restrict__ points, con
     return conds ? conds[b * 12 + (i - 3 * K)] : 0.0;
 }
 
-// C <= 64: lane <-> control point, its row of A+ in registers (RMAX >= K + 4)
-template <int RMAX>
+// C <= 64: lane <-> control point, its row of A+ in registers (KMAX >= K).  A path's right-hand
+// side is the same for every lane: its addresses are wave-uniform, so the compiler fetches it with
+// scalar loads (s_load_dwordx*, scalar cache) and the FMAs take it as SGPR operands — no LDS
+// staging, no barriers; the lanes' only vector memory traffic is the coalesced 24-byte store.
+template <int KMAX>
 __global__ void __launch_bounds__(64) k_bspline_fit_reg(int B, int K, const double* __restrict__ pinvT,
                                                         const double* __restrict__ points,
                                                         const double* __restrict__ conds, double* __restrict__ out) {
-    const int R = K + 4, C = K + 2;
+    const int C = K + 2;
     const int row = threadIdx.x;
-    __shared__ double in[RMAX * 3];
-    double P[RMAX];
+    double P[KMAX], Pc[4];
 #pragma unroll
-    for (int j = 0; j < RMAX; ++j) P[j] = (j < R && row < C) ? pinvT[(size_t)j * C + row] : 0.0;
+    for (int j = 0; j < KMAX; ++j) P[j] = (j < K && row < C) ? pinvT[(size_t)j * C + row] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Pc[i] = row < C ? pinvT[(size_t)(K + i) * C + row] : 0.0;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        for (int i = threadIdx.x; i < 3 * R; i += 64) in[i] = fit_rhs(points, conds, (size_t)b, K, i);
-        __syncthreads();
+        const double* __restrict__ pt = points + (size_t)b * 3 * K;
         double ax = 0.0, ay = 0.0, az = 0.0;
+        // rows in chunks of 8 behind ONE uniform branch each: a full chunk's 24 doubles are
+        // contiguous, so the compiler fetches them with a few wide scalar loads issued together;
+        // the last, partial chunk re-reads the final waypoint with zero coefficients (+0 terms)
 #pragma unroll
-        for (int j = 0; j < RMAX; ++j) {
-            if (j < R) {
-                ax += P[j] * in[3 * j];
-                ay += P[j] * in[3 * j + 1];
-                az += P[j] * in[3 * j + 2];
+        for (int j0 = 0; j0 < KMAX; j0 += 8) {
+            if (j0 + 8 <= K) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    if (j0 + jj < KMAX) {
+                        ax = __builtin_fma(P[j0 + jj], pt[3 * (j0 + jj)], ax);
+                        ay = __builtin_fma(P[j0 + jj], pt[3 * (j0 + jj) + 1], ay);
+                        az = __builtin_fma(P[j0 + jj], pt[3 * (j0 + jj) + 2], az);
+                    }
+                }
+            } else if (j0 < K) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    if (j0 + jj < KMAX) {
+                        const int jc = j0 + jj < K ? j0 + jj : K - 1;
+                        ax = __builtin_fma(P[j0 + jj], pt[3 * jc], ax);
+                        ay = __builtin_fma(P[j0 + jj], pt[3 * jc + 1], ay);
+                        az = __builtin_fma(P[j0 + jj], pt[3 * jc + 2], az);
+                    }
+                }
             }
         }
+        if (conds) {
+            const double* __restrict__ cd = conds + (size_t)b * 12;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ax = __builtin_fma(Pc[i], cd[3 * i], ax);
+                ay = __builtin_fma(Pc[i], cd[3 * i + 1], ay);
+                az = __builtin_fma(Pc[i], cd[3 * i + 2], az);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ax = __builtin_fma(Pc[i], 0.0, ax); ay = __builtin_fma(Pc[i], 0.0, ay); az = __builtin_fma(Pc[i], 0.0, az); }   // same sums as with zero conditions
+        }
+#if VIGO_FIT_LDS_STORE
+        // [row][3] -> linear order through LDS, so each store instruction writes 512 contiguous bytes
+        __shared__ double ob[64 * 3];
+        ob[3 * row] = ax; ob[3 * row + 1] = ay; ob[3 * row + 2] = az;
+        __syncthreads();
+        double* dst = out + (size_t)b * C * 3;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            if (row + 64 * e < 3 * C) dst[row + 64 * e] = ob[row + 64 * e];
+        __syncthreads();
+#else
         if (row < C) {
             double* dst = out + ((size_t)b * C + row) * 3;
             dst[0] = ax; dst[1] = ay; dst[2] = az;
         }
-        __syncthreads();
+#endif
     }
 }
 
@@ -151,9 +198,9 @@ __global__ void __launch_bounds__(256) k_bspline_fit_gen(int B, int K, const dou
             double ax = 0.0, ay = 0.0, az = 0.0;
             for (int j = 0; j < R; ++j) {
                 const double p = pinvT[(size_t)j * C + row];
-                ax += p * in[3 * j];
-                ay += p * in[3 * j + 1];
-                az += p * in[3 * j + 2];
+                ax = __builtin_fma(p, in[3 * j], ax);
+                ay = __builtin_fma(p, in[3 * j + 1], ay);
+                az = __builtin_fma(p, in[3 * j + 2], az);
             }
             double* dst = out + ((size_t)b * C + row) * 3;
             dst[0] = ax; dst[1] = ay; dst[2] = az;
@@ -176,10 +223,10 @@ int launch_bspline_fit(hipStream_t s, int B, int K, const double* pinvT, const d
                        double* out) {
     if (B <= 0) return hipSuccess;
     const int grid = B < 4096 ? B : 4096;  // 16 waves per CU worth of workgroups, grid-stride beyond
-    if (K + 4 <= 36)
-        hipLaunchKernelGGL((k_bspline_fit_reg<36>), dim3(grid), dim3(64), 0, s, B, K, pinvT, points, conds, out);
+    if (K <= 32)
+        hipLaunchKernelGGL((k_bspline_fit_reg<32>), dim3(grid), dim3(64), 0, s, B, K, pinvT, points, conds, out);
     else if (K + 2 <= 64)  // one lane per control point: C = K + 2 rows must fit the wave
-        hipLaunchKernelGGL((k_bspline_fit_reg<66>), dim3(grid), dim3(64), 0, s, B, K, pinvT, points, conds, out);
+        hipLaunchKernelGGL((k_bspline_fit_reg<62>), dim3(grid), dim3(64), 0, s, B, K, pinvT, points, conds, out);
     else
         hipLaunchKernelGGL(k_bspline_fit_gen, dim3(grid), dim3(256), 0, s, B, K, pinvT, points, conds, out);
     return (int)hipGetLastError();

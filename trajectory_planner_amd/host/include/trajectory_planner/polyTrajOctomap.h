@@ -69,6 +69,11 @@ public:
     void setSolution(int polyDegree, const std::vector<double>& xSol, const std::vector<double>& ySol,
                      const std::vector<double>& zSol, const std::vector<double>& timeKnot);
 
+    /* makePlan() of many planners in lock-step (corridor-constraint mode, PO.cpp:388-545): per round ONE
+     * vigo_minsnap launch solves every active planner's QP and ONE vigo_box_collision_points launch sweeps
+     * every sample of every candidate trajectory; corridor bookkeeping and the PWL fallback stay per planner.
+     * trajectories[i] receives planner i's samples (delT = its sample_delta_time). */
+    static std::vector<bool> makePlanBatch(const std::vector<polyTrajOctomap*>& planners, std::vector<std::vector<pose>>& trajectories);
     void makePlan();
     void makePlan(nav_msgs::Path& trajectory, double delT);
     void makePlan(std::vector<pose>& trajectory, double delT);

@@ -57,6 +57,9 @@ public:
     void updateEndAcc(double ax, double ay, double az);
     void setCorridorConstraint(const std::vector<double>& corridorSizeVec, double corridorRes);
     void setCorridorConstraint(double corridorSize, double corridorRes);
+    /* install coefficients computed elsewhere (vigo_minsnap on the device) for the current path;
+     * un-normalised local time, (deg+1) per segment; knots must be getTimeKnot()'s */
+    void installSolution(const std::vector<double>& x, const std::vector<double>& y, const std::vector<double>& z);
     bool solve();   // the reference's solve() is void and silently keeps a stale solution on failure
     pose getPose(double t);
     void getTrajectory(std::vector<pose>& trajectory, double delT);

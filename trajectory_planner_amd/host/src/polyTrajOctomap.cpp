@@ -295,6 +295,129 @@ void polyTrajOctomap::makePlan(std::vector<pose>& trajectory, double delT) {
     }
 }
 
+std::vector<bool> polyTrajOctomap::makePlanBatch(const std::vector<polyTrajOctomap*>& ps, std::vector<std::vector<pose>>& trajectories) {
+    const size_t P = ps.size();
+    std::vector<bool> result(P, false);
+    trajectories.assign(P, {});
+    if (P == 0) return result;
+    // planners the device path cannot take (adding-waypoint mode, installed polynomial, too many or too few
+    // waypoints, another polynomial degree) plan on their own
+    std::vector<size_t> grp;
+    for (size_t i = 0; i < P; ++i) {
+        polyTrajOctomap* p = ps[i];
+        p->findValidTraj_ = false;
+        const bool batchable = !p->mode_ && p->extKnots_.empty() && p->path_.size() >= 2 && p->path_.size() <= 11 && p->polyDegree_ == 7 &&
+                               p->path_.size() == ps[0]->path_.size() && p->diffDegree_ == ps[0]->diffDegree_ &&
+                               p->continuityDegree_ == ps[0]->continuityDegree_ && p->desiredVel_ == ps[0]->desiredVel_ &&
+                               p->corridorRes_ == ps[0]->corridorRes_ && p->map_ == ps[0]->map_;
+        if (batchable) grp.push_back(i);
+        else { p->makePlan(trajectories[i], p->delT_); result[i] = p->findValidTraj_; }
+    }
+    if (grp.empty()) return result;
+    polyTrajOctomap* lead = ps[grp[0]];
+    if (!lead->syncDevice()) return result;
+    const int W = (int)lead->path_.size(), K = W - 1, D = 8;
+    struct State { std::vector<double> corridor; int iters = 0; bool active = true; double t0 = 0; };
+    std::vector<State> st(grp.size());
+    for (size_t g = 0; g < grp.size(); ++g) {
+        polyTrajOctomap* p = ps[grp[g]];
+        p->setDefaultInit();
+        p->trajSolver_.reset(new polyTrajSolver(p->polyDegree_, p->diffDegree_, p->continuityDegree_, p->desiredVel_));
+        p->trajSolver_->updatePath(p->path_);
+        st[g].corridor.assign(K, p->initR_);
+        st[g].t0 = nowSec();
+    }
+    void *dWp = nullptr, *dCor = nullptr, *dCo = nullptr, *dKn = nullptr, *dSt = nullptr, *dPts = nullptr, *dFl = nullptr;
+    size_t ptsCap = 0;
+    const size_t G = grp.size();
+    bool ok = hipMalloc(&dWp, G * W * 24) == hipSuccess && hipMalloc(&dCor, G * K * 8) == hipSuccess && hipMalloc(&dCo, G * K * 3 * D * 8) == hipSuccess &&
+              hipMalloc(&dKn, G * W * 8) == hipSuccess && hipMalloc(&dSt, G * 4) == hipSuccess;
+    std::vector<double> hWp, hCor, hCo(G * K * 3 * D);
+    std::vector<int32_t> hSt(G);
+    while (ok) {
+        std::vector<size_t> act;
+        for (size_t g = 0; g < G; ++g) if (st[g].active) act.push_back(g);
+        if (act.empty()) break;
+        const int T = (int)act.size();
+        hWp.clear(); hCor.clear();
+        for (size_t g : act) {
+            for (const pose& q : ps[grp[g]]->path_) { hWp.push_back(q.x); hWp.push_back(q.y); hWp.push_back(q.z); }
+            hCor.insert(hCor.end(), st[g].corridor.begin(), st[g].corridor.end());
+        }
+        ok = hipMemcpy(dWp, hWp.data(), hWp.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(dCor, hCor.data(), hCor.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+             vigo_minsnap(lead->dev_, T, W, 7, lead->diffDegree_, lead->continuityDegree_, lead->desiredVel_, lead->corridorRes_, (const double*)dWp,
+                          (const double*)dCor, nullptr, (double*)dCo, (double*)dKn, (int32_t*)dSt) == VIGO_OK &&
+             hipDeviceSynchronize() == hipSuccess && hipMemcpy(hCo.data(), dCo, (size_t)T * K * 3 * D * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(hSt.data(), dSt, (size_t)T * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok) break;
+        // install the solutions (an infeasible corridor keeps the previous one, like the reference), sample, sweep all at once
+        std::vector<double> pts;
+        std::vector<size_t> first(T + 1, 0);
+        for (int a = 0; a < T; ++a) {
+            polyTrajOctomap* p = ps[grp[act[a]]];
+            if (hSt[a] == 0) {
+                std::vector<double> xs(K * D), ys(K * D), zs(K * D);
+                for (int sgm = 0; sgm < K; ++sgm)
+                    for (int d = 0; d < D; ++d) {
+                        xs[sgm * D + d] = hCo[(((size_t)a * K + sgm) * 3 + 0) * D + d];
+                        ys[sgm * D + d] = hCo[(((size_t)a * K + sgm) * 3 + 1) * D + d];
+                        zs[sgm * D + d] = hCo[(((size_t)a * K + sgm) * 3 + 2) * D + d];
+                    }
+                p->trajSolver_->installSolution(xs, ys, zs);
+            }
+            p->trajSolver_->getTrajectory(trajectories[grp[act[a]]], p->delT_);
+            for (const pose& q : trajectories[grp[act[a]]]) { pts.push_back(q.x); pts.push_back(q.y); pts.push_back(q.z); }
+            first[a + 1] = pts.size() / 3;
+        }
+        const size_t M = pts.size() / 3;
+        if (M > ptsCap) {
+            if (dPts) (void)hipFree(dPts);
+            if (dFl) (void)hipFree(dFl);
+            dPts = dFl = nullptr;
+            ok = hipMalloc(&dPts, M * 24) == hipSuccess && hipMalloc(&dFl, M) == hipSuccess;
+            ptsCap = ok ? M : 0;
+            if (!ok) break;
+        }
+        std::vector<uint8_t> flags(M, 1);
+        const double box[3] = {lead->collisionBox_[0], lead->collisionBox_[1], lead->collisionBox_[2]};
+        ok = hipMemcpy(dPts, pts.data(), M * 24, hipMemcpyHostToDevice) == hipSuccess &&
+             vigo_box_collision_points(lead->dev_, (int64_t)M, (const double*)dPts, box, lead->mapRes_, (uint8_t*)dFl) == VIGO_OK &&
+             hipDeviceSynchronize() == hipSuccess && hipMemcpy(flags.data(), dFl, M, hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok) break;
+        for (int a = 0; a < T; ++a) {
+            const size_t g = act[a];
+            polyTrajOctomap* p = ps[grp[g]];
+            const std::vector<double>& knots = p->trajSolver_->getTimeKnot();
+            std::set<int> collisionSeg;   // PO.cpp:634-656
+            double t = 0;
+            bool has = false;
+            for (size_t k = first[a]; k < first[a + 1]; ++k) {
+                if (flags[k]) {
+                    has = true;
+                    for (size_t i = 0; i + 1 < knots.size(); ++i)
+                        if (t >= knots[i] && t <= knots[i + 1]) { collisionSeg.insert((int)i); break; }
+                }
+                t += p->delT_;
+            }
+            ++st[g].iters;
+            if (!has) { p->findValidTraj_ = true; st[g].active = false; }
+            else {
+                for (int sgm : collisionSeg) st[g].corridor[sgm] *= p->fs_;   // adjustCorridorSize, PO.cpp:188-192
+                if (st[g].iters > p->maxIter_ || nowSec() - st[g].t0 >= p->timeout_ * (double)G) st[g].active = false;
+            }
+            p->lastIterations_ = st[g].iters;
+        }
+    }
+    for (void* q : {dWp, dCor, dCo, dKn, dSt, dPts, dFl}) if (q) (void)hipFree(q);
+    for (size_t g = 0; g < G; ++g) {
+        polyTrajOctomap* p = ps[grp[g]];
+        if (!p->findValidTraj_) { p->trajSolver_.reset(); p->pwlPlan(trajectories[grp[g]], p->delT_); }   // PO.cpp:459-467
+        result[grp[g]] = p->findValidTraj_;
+    }
+    return result;
+}
+
 void polyTrajOctomap::makePlan() {
     std::vector<pose> trajectory;
     this->makePlan(trajectory, this->delT_);

@@ -459,6 +459,11 @@ bool polyTrajSolver::solve() {
     return ok;
 }
 
+void polyTrajSolver::installSolution(const std::vector<double>& x, const std::vector<double>& y, const std::vector<double>& z) {
+    xSol_ = x; ySol_ = y; zSol_ = z;
+    solved_ = true;
+}
+
 // PS.cpp:1026-1056
 pose polyTrajSolver::getPose(double t) {
     pose p;

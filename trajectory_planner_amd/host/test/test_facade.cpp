@@ -184,6 +184,47 @@ int main() {
         CHECK(std::fabs(poly.getDuration() - 6.0) < 1e-12 && std::fabs(poly.getPose(1.5).pose.position.x + 1.5) < 1e-12, "getDuration / getPose");
     }
 
+    // ---- polyTrajOctomap::makePlanBatch: 24 waypoint paths beside / through the pillar, one QP launch + one sweep launch per round ----
+    {
+        std::vector<std::unique_ptr<trajPlanner::polyTrajOctomap>> owners;
+        std::vector<trajPlanner::polyTrajOctomap*> ps;
+        for (int i = 0; i < 24; ++i) {
+            ros::NodeHandle nh;
+            nh.setParam("collision_box", std::vector<double>{0.4, 0.4, 0.2});
+            nh.setParam("map_resolution", 0.2);
+            nh.setParam("sample_delta_time", 0.1);
+            nh.setParam("mode", 0.0);
+            nh.setParam("initial_radius", 0.5);
+            nh.setParam("shrinking_factor", 0.8);
+            nh.setParam("corridor_res", 8.0);
+            nh.setParam("maximum_iteration_num", 30.0);
+            nh.setParam("traj_timeout", 0.5);
+            owners.emplace_back(new trajPlanner::polyTrajOctomap(nh));
+            owners.back()->setMap(map);
+            const double y = 1.6 + 0.12 * i;   // legs pass the pillar (|y| <= 0.8 + margin) at increasing distance
+            owners.back()->updatePath(std::vector<trajPlanner::pose>{{-3, y, 1}, {-1, y + 0.3, 1}, {1, y + 0.3, 1}, {3, y, 1}});
+            ps.push_back(owners.back().get());
+        }
+        std::vector<std::vector<trajPlanner::pose>> trajs;
+        std::vector<bool> res = trajPlanner::polyTrajOctomap::makePlanBatch(ps, trajs);
+        int valid = 0, agree = 0;
+        for (size_t i = 0; i < ps.size(); ++i) {
+            valid += res[i];
+            std::vector<int> idx;
+            const bool hit = ps[i]->checkCollisionTraj(trajs[i], idx);
+            agree += (res[i] == !hit) || !res[i];
+        }
+        // the same planner alone gives the same answer and the same trajectory
+        trajPlanner::polyTrajOctomap* solo = ps[3];
+        std::vector<trajPlanner::pose> t2;
+        solo->makePlan(t2, 0.1);
+        double worst = 0;
+        for (size_t k = 0; k < t2.size() && k < trajs[3].size(); ++k) worst = std::fmax(worst, std::fabs(t2[k].x - trajs[3][k].x) + std::fabs(t2[k].y - trajs[3][k].y));
+        std::printf("INFO poly batch: %d of %zu valid; solo-vs-batch max diff %.3e\n", valid, ps.size(), worst);
+        CHECK(valid >= 20 && agree == (int)ps.size(), "polyTrajOctomap::makePlanBatch: valid plans are collision free");
+        CHECK(t2.size() == trajs[3].size() && worst < 1e-6 && solo->isValid() == res[3], "batch plan == single makePlan (device QP == host QP)");
+    }
+
     std::printf("%s (%d failures)\n", fails ? "FAILED" : "PASSED", fails);
     return fails ? 1 : 0;
 }
