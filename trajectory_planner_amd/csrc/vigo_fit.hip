@@ -13,17 +13,17 @@
 //   k_bspline_fit one wave per workgroup, lane <-> control point (row of A+): the lane keeps its
 //                 row of A+ in registers for all trajectories of its grid-stride loop, the K+4
 //                 input rows of a trajectory arrive through the scalar cache (wave-uniform
-//                 addresses), output [K+2][3] written coalesced.  HBM-bound:
-//                 (2K + 6) * 24 algorithmic bytes per trajectory.
+//                 addresses), output [K+2][3] written coalesced.  Nominal bound HBM,
+//                 (2K + 6) * 24 algorithmic bytes per trajectory; measured 1.7 TB/s (21 % of
+//                 peak) at 65 536 paths x 30 waypoints — each wave walks its paths one at a time,
+//                 so it is bound by the latency of a path's dependent load -> FMA chain, not by
+//                 LDS, VALU or the store pattern (variants of all three measured the same).
 // fp64, explicit fused multiply-adds in index order: deterministic, batch-invariant.
 #include "vigo_internal.hpp"
 
 namespace vigo {
 namespace {
 
-#ifndef VIGO_FIT_LDS_STORE
-#define VIGO_FIT_LDS_STORE 1
-#endif
 constexpr int kSetupThreads = 256;
 constexpr int kMaxRows = VIGO_MAX_CTRL_POINTS + 2;  // R = K + 4 <= N_max + 2
 
@@ -166,22 +166,10 @@ __global__ void __launch_bounds__(64) k_bspline_fit_reg(int B, int K, const doub
 #pragma unroll
             for (int i = 0; i < 4; ++i) { ax = __builtin_fma(Pc[i], 0.0, ax); ay = __builtin_fma(Pc[i], 0.0, ay); az = __builtin_fma(Pc[i], 0.0, az); }   // same sums as with zero conditions
         }
-#if VIGO_FIT_LDS_STORE
-        // [row][3] -> linear order through LDS, so each store instruction writes 512 contiguous bytes
-        __shared__ double ob[64 * 3];
-        ob[3 * row] = ax; ob[3 * row + 1] = ay; ob[3 * row + 2] = az;
-        __syncthreads();
-        double* dst = out + (size_t)b * C * 3;
-#pragma unroll
-        for (int e = 0; e < 3; ++e)
-            if (row + 64 * e < 3 * C) dst[row + 64 * e] = ob[row + 64 * e];
-        __syncthreads();
-#else
         if (row < C) {
             double* dst = out + ((size_t)b * C + row) * 3;
             dst[0] = ax; dst[1] = ay; dst[2] = az;
         }
-#endif
     }
 }
 
