@@ -22,6 +22,8 @@
 // of glibc pow(x,2|3), sqrt instead of pow(.,0.5).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "vigo_internal.hpp"
 
 namespace vigo {
@@ -695,6 +697,9 @@ __device__ __forceinline__ int trial_interval(double& xt, double& xf, double& xd
 #ifndef VIGO_TWOLOOP_WIN
 #define VIGO_TWOLOOP_WIN 2
 #endif
+#ifndef VIGO_TWOLOOP_STEADY
+#define VIGO_TWOLOOP_STEADY 1
+#endif
 template <typename T, int GROUP, int PPL, bool FAST>
 __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevConst* __restrict__ Kp) {
     const DevConst& K = *Kp;  // uniform address: scalar loads at the use sites, not 100+ live SGPRs
@@ -953,54 +958,103 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
             }
             ys_ = ys_l[slot * TPB];
         };
-#pragma unroll
-        for (int q = 0; q < PPL; ++q)
-#pragma unroll
-            for (int a = 0; a < 3; ++a) { Ps[0][q][a] = sv[q][a]; Py[0][q][a] = yv[q][a]; }
-        Pys[0] = ys_div;
-#pragma unroll
-        for (int age = 1; age < kWin; ++age)
-            if (age < bound) fetch(age, Ps[age], Py[age], Pys[age]);
-#pragma unroll
-        for (int age = 0; age < kMaxMem; ++age) {      // newest -> oldest, LB:1294-1303
-            if (age < bound) {
-                const int w = age % kWin;
-                double al = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(Ps[w], d));
-                if (FAST) al *= Pys[w]; else al /= Pys[w];
-                al_l[age * TPB] = al;                  // alpha_j parks in LDS at a static offset
+        // STEADY: the history is full (bound == kMaxMem, every iteration after the 16th): `age <
+        // bound` is true at compile time, so the 32 steps are straight-line code — no exec-mask
+        // blocks, no merge copies of the window registers, LDS fetches hoisted freely — and the
+        // alphas stay in registers.  Same operations in the same order as the general path.
+        auto two_loop = [&](auto steady_tag) {
+            constexpr bool STEADY = decltype(steady_tag)::value;
+            const int bnd = STEADY ? kMaxMem : bound;
+            double al_reg[STEADY ? kMaxMem : 1];
+            // STEADY: the LDS ring (kMaxMem - 2 slots) is walked with running byte offsets — one
+            // add and a wrap per fetch instead of slot arithmetic and two quarter-rate multiplies
+            constexpr int kRing = kMaxMem - 2;
+            const int stepB = ROW * (int)sizeof(HPair<T>), stepY = TPB * (int)sizeof(double);
+            int curB = last * stepB, curY = last * stepY;   // slot of the age-2 pair
+            auto ring_fetch = [&](T (&s_)[PPL][3], T (&y_)[PPL][3], double& ys_) {
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) {
-                    const T na = Q.interior[q] ? (T)(-al) : T(0);
+                    const HPair<T> h = *reinterpret_cast<const HPair<T>*>(reinterpret_cast<const char*>(hl[q]) + curB);
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) d[q][a] = FAST ? fmaT(na, Py[w][q][a], d[q][a]) : d[q][a] + na * Py[w][q][a];
+                    for (int a = 0; a < 3; ++a) { s_[q][a] = h.s[a]; y_[q][a] = h.y[a]; }
                 }
-                if (age + kWin < kMaxMem && age + kWin < bound) fetch(age + kWin, Ps[w], Py[w], Pys[w]);
-            }
-        }
-        {
-            const T sc = (T)(ys / yy);  // LB:1305
+                ys_ = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ys_l) + curY);
+            };
+            auto ring_older = [&]() {   // towards higher ages: one slot down, wrapping
+                curB -= stepB; curY -= stepY;
+                if (curB < 0) { curB += kRing * stepB; curY += kRing * stepY; }
+            };
+            auto ring_newer = [&]() {
+                curB += stepB; curY += stepY;
+                if (curB >= kRing * stepB) { curB -= kRing * stepB; curY -= kRing * stepY; }
+            };
 #pragma unroll
             for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                for (int a = 0; a < 3; ++a) d[q][a] *= sc;
-        }
-        // the window now holds the ages [max(0, bound - kWin), bound)
+                for (int a = 0; a < 3; ++a) { Ps[0][q][a] = sv[q][a]; Py[0][q][a] = yv[q][a]; }
+            Pys[0] = ys_div;
 #pragma unroll
-        for (int age = kMaxMem - 1; age >= 0; --age) {  // oldest -> newest, LB:1307-1316
-            if (age < bound) {
-                const int w = age % kWin;
-                double beta = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(Py[w], d));
-                if (FAST) beta *= Pys[w]; else beta /= Pys[w];
-                const double cod = al_l[age * TPB] - beta;
+            for (int age = 1; age < kWin; ++age)
+                if (age < bnd) fetch(age, Ps[age], Py[age], Pys[age]);
 #pragma unroll
-                for (int q = 0; q < PPL; ++q) {
-                    const T co = Q.interior[q] ? (T)cod : T(0);
+            for (int age = 0; age < kMaxMem; ++age) {      // newest -> oldest, LB:1294-1303
+                if (age < bnd) {
+                    const int w = age % kWin;
+                    double al = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(Ps[w], d));
+                    if (FAST) al *= Pys[w]; else al /= Pys[w];
+                    if (STEADY) al_reg[STEADY ? age : 0] = al;
+                    else al_l[age * TPB] = al;         // alpha_j parks in LDS at a static offset
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) d[q][a] = FAST ? fmaT(co, Ps[w][q][a], d[q][a]) : d[q][a] + co * Ps[w][q][a];
+                    for (int q = 0; q < PPL; ++q) {
+                        const T na = Q.interior[q] ? (T)(-al) : T(0);
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) d[q][a] = FAST ? fmaT(na, Py[w][q][a], d[q][a]) : d[q][a] + na * Py[w][q][a];
+                    }
+                    if (age + kWin < kMaxMem && age + kWin < bnd) {
+                        if (STEADY && age + kWin >= 2) { ring_fetch(Ps[w], Py[w], Pys[w]); ring_older(); }
+                        else fetch(age + kWin, Ps[w], Py[w], Pys[w]);
+                    }
                 }
-                if (age - kWin >= 0) fetch(age - kWin, Ps[w], Py[w], Pys[w]);
             }
-        }
+            if (STEADY) {
+                // the ring pointer has gone once around (age kMaxMem == age 2's slot); the second
+                // loop starts fetching at age kMaxMem - 1 - kWin.  The compiler must not keep the
+                // first loop's 14 pairs alive in AGPRs for it (24 register moves per pair cost more
+                // VALU slots than three ds_read_b128): LDS is declared clobbered here.
+#pragma unroll
+                for (int i = 0; i < kWin + 1; ++i) ring_newer();
+                asm volatile("" ::: "memory");
+            }
+            {
+                const T sc = (T)(ys / yy);  // LB:1305
+#pragma unroll
+                for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) d[q][a] *= sc;
+            }
+            // the window now holds the ages [max(0, bound - kWin), bound)
+#pragma unroll
+            for (int age = kMaxMem - 1; age >= 0; --age) {  // oldest -> newest, LB:1307-1316
+                if (age < bnd) {
+                    const int w = age % kWin;
+                    double beta = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(Py[w], d));
+                    if (FAST) beta *= Pys[w]; else beta /= Pys[w];
+                    const double cod = (STEADY ? al_reg[STEADY ? age : 0] : al_l[age * TPB]) - beta;
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) {
+                        const T co = Q.interior[q] ? (T)cod : T(0);
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) d[q][a] = FAST ? fmaT(co, Ps[w][q][a], d[q][a]) : d[q][a] + co * Ps[w][q][a];
+                    }
+                    if (age - kWin >= 0) {
+                        if (STEADY && age - kWin >= 2) { ring_fetch(Ps[w], Py[w], Pys[w]); ring_newer(); }
+                        else fetch(age - kWin, Ps[w], Py[w], Pys[w]);
+                    }
+                }
+            }
+        };
+        if (VIGO_TWOLOOP_STEADY && PPL == 1 && bound == kMaxMem) two_loop(std::true_type{});
+        else two_loop(std::false_type{});
         if (REG1) {
             // the age-1 pair turns age 2 for the next two-loop: it leaves the registers for the LDS
             // ring (overwriting the pair that would be age m), the new pair takes its place
