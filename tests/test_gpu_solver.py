@@ -252,3 +252,36 @@ def test_fast_mode_matches_its_emulation_and_the_reference_gate(vigo_handle, sma
     print(f"\n[fast N={N}] vs reference-order oracle: median {np.median(rel):.2e} p99 {np.quantile(rel, .99):.2e} max {rel.max():.2e}")
     assert (rel <= TOL).mean() >= 0.99 and np.median(rel) < 1e-8
     v.set_precision(PREC_F64)
+
+
+@pytest.mark.parametrize("name,n,n_boxes,centre,B,N,start", [("configs[1]", 256, 200, 12.0, 1024, 32, 8.0),
+                                                            ("configs[3] shard", 512, 800, 24.0, 8192, 64, 16.0)])
+def test_baseline_sizes_in_full(vigo_handle, name, n, n_boxes, centre, B, N, start):
+    """BASELINE.json configs[1] (1024 x 32, 256^3) and one GPU's shard of configs[3] (8192 x 64, 512^3) at FULL
+    size, the bench.py workloads themselves: every trajectory bit-exact vs the emulation-mode oracle and
+    within 1e-4 of the reference-order oracle (the oracle needs ~0.1 s / ~5 s for them)."""
+    v = vigo_handle
+    cfg = 2 if N == 32 else 4
+    world = synth.make_box_world(synth.SEED_BASE + cfg, n=n, n_boxes=n_boxes, centre_range=centre)
+    b = synth.make_bspline_batch(world, B, N, synth.SEED_BASE + cfg + 1000, start_range=start)
+    P = default_params()
+    P.max_iterations = 50
+    v.set_params(P)
+    v.set_grid(to_dev(world.voxels, v.device), world.origin, world.res)
+    d = batch_to_dev(b, v.device)
+    gunk = v.guides_unknown(d["guide_pv"])
+    assert np.array_equal(gunk.cpu().numpy(), b.guide_unk)
+    d["guide_unk"] = gunk
+    r = v.optimize(**d)
+    g = {k: getattr(r, k).cpu().numpy() for k in ("ctrl", "x", "status", "fx", "iters", "evals")}
+    with emulation(N):
+        e = ol.optimize_batch(P, b)
+    for k in ("status", "iters", "evals", "x", "ctrl", "fx"):
+        assert np.array_equal(g[k], e[k]), f"{name}: {k} differs from the emulation-mode oracle"
+    ref = ol.optimize_batch(P, b)
+    rel = rel_err_per_traj(g["ctrl"], ref["ctrl"])
+    print(f"\n[{name}: {B} x {N}] vs reference-order oracle: median {np.median(rel):.2e} p99 {np.quantile(rel, .99):.2e} "
+          f"max {rel.max():.2e}; within 1e-4: {(rel <= TOL).mean() * 100:.2f} %")
+    assert (rel <= TOL).mean() >= 0.995 and np.median(rel) < 1e-8
+    # fixed boundary control points never move (BT.cpp:690-691)
+    assert np.array_equal(g["ctrl"][:, :3], b.ctrl[:, :3]) and np.array_equal(g["ctrl"][:, -3:], b.ctrl[:, -3:])

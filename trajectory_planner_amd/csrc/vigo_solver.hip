@@ -277,7 +277,11 @@ __device__ __forceinline__ void obstacle_term(const DevConst& K, const T (&c)[3]
             const T ct = cubic ? (e * e) * e : (oa * (e * e) + ob * e) + oc;
             const T k = cubic ? T(-3.0) * (e * e) : -((T(2) * oa) * e + ob);
             co += (double)ct;
-            Go[0] += k * (dx / nrm); Go[1] += k * (dy / nrm); Go[2] += k * (dz / nrm);
+            Go[0] += k * (dx / nrm); Go[1] += k * (dy / nrm);
+            // diff.z = 0 (BT.cpp:1022): for a finite positive |diff| the z term is k * (+0) = +-0 and
+            // leaves the +0 (or NaN) accumulator as it is, so its fp64 division is only issued in
+            // the degenerate cases (control point exactly on the predicted centre, NaN/inf input)
+            if (__builtin_expect(!(nrm > T(0) && nrm < (T)INFINITY), 0)) Go[2] += k * (dz / nrm);
         }
     }
 }
