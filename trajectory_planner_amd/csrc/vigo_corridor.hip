@@ -22,18 +22,21 @@ constexpr int kChunk = 16;       // consecutive samples per thread visit
 constexpr int kBlock = 256;
 constexpr int kMaxDeg = 15;
 
+// collision_box / map_resolution of the sweep and octomap's resolution_factor (1 / tree resolution)
+struct SweepConst {
+    double box[3], map_res, rf;
+};
+
 struct CorridorArgs {
     int S, deg;
     const double* coeffs;
     const int32_t* n_samp;
     const double* delT;
-    double box[3];
-    double map_res;
-    double rf;  // 1.0 / grid.res (octomap resolution_factor)
     uint8_t* out_flag;
     int32_t* out_first;
     int32_t* out_count;
     int tile_words_cap;
+    SweepConst sweep;
 };
 
 // PS.cpp:1035-1039: x += c[d] * pow(t, d), d ascending (powers by repeated multiplication)
@@ -52,11 +55,102 @@ __device__ __forceinline__ void poly_pos(const double* cf, int deg, double t, do
 __device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
+// ---- the box sweep of one pose (polyTrajOctomap::checkCollision, PO.cpp:547-568) -----------
+// The reference walks the lattice xi, yi, zi and returns at the first point that is outside the
+// metric bounds, outside the tree (unknown) or occupied; only the boolean leaves the function, so
+// the result is the OR over all lattice points and the walk order is free.  Per axis the lattice
+// coordinate, its bounds test and its voxel key depend on that axis' index alone: they are
+// evaluated once per axis point (3 + 3 + 2 for the cfg box) instead of once per lattice point
+// (3 + 9 + 18), with exactly the reference's expressions (float coordinates, PO.cpp:558-560;
+// floor(coord * resolution_factor) keys, octomap coordToKey).
+constexpr int kAxisMax = 4;  // lattice points per axis on the fast path (box / map_res <= 3)
+
+__device__ __forceinline__ void axis_keys(double lo, int num, double map_res, double rf, double bmin, double bmax,
+                                          int key0, int dim, int (&k)[kAxisMax], bool& out) {
+#pragma unroll
+    for (int i = 0; i < kAxisMax; ++i) {
+        k[i] = 0;
+        if (i <= num) {
+            const float q = (float)(lo + i * map_res);
+            out |= (q < bmin) || (q > bmax);                       // PO.cpp:572-577 metric bounds
+            const int kk = (int)floor(rf * (double)q) - key0;
+            out |= (kk < 0) || (kk >= dim);                        // no node there: unknown -> occupied
+            k[i] = kk;
+        }
+    }
+}
+
 struct Tile {
     int x0, y0, w0;      // first voxel x, y and first z-word covered
     int tx, ty, tw;      // extent in x, y voxels and z words
     bool in_lds;
 };
+
+// polyTrajOctomap::checkCollision(point3d) for one pose.  T != nullptr: look the voxels up in the LDS
+// tile when it holds them (it does by construction of the tile; the test costs six compares per pose).
+__device__ __forceinline__ bool box_sweep(const GridView& g, const SweepConst& C, float fx, float fy, float fz,
+                                          const Tile* T, const uint32_t* tile_words) {
+    const double map_res = C.map_res, rf = C.rf;
+    // PO.cpp:548-555
+    const double xmin = fx - C.box[0] / 2, xmax = fx + C.box[0] / 2;
+    const double ymin = fy - C.box[1] / 2, ymax = fy + C.box[1] / 2;
+    const double zmin = fz - C.box[2] / 2, zmax = fz + C.box[2] / 2;
+    // truncation of a ROUNDED quotient whose dividend wobbles by an ulp of fx around the box size: the
+    // count can be one short, per pose (replacing the divisions by compares against host-bisected
+    // thresholds gives the same integers but measured 5 % slower)
+    const int xNum = (int)((xmax - xmin) / map_res);
+    const int yNum = (int)((ymax - ymin) / map_res);
+    const int zNum = (int)((zmax - zmin) / map_res);
+    bool hit = false;
+    if (xNum < kAxisMax && yNum < kAxisMax && zNum < kAxisMax && xNum >= 0 && yNum >= 0 && zNum >= 0) {
+        int kx[kAxisMax], ky[kAxisMax], kz[kAxisMax];
+        axis_keys(xmin, xNum, map_res, rf, g.bmin[0], g.bmax[0], g.key0[0], g.nx, kx, hit);
+        axis_keys(ymin, yNum, map_res, rf, g.bmin[1], g.bmax[1], g.key0[1], g.ny, ky, hit);
+        axis_keys(zmin, zNum, map_res, rf, g.bmin[2], g.bmax[2], g.key0[2], g.nz, kz, hit);
+        if (hit) return true;
+        // keys grow with the lattice index: the tile holds all of them iff it holds the first and last
+        const bool tiled = T && T->in_lds && kx[0] >= T->x0 && kx[xNum] < T->x0 + T->tx && ky[0] >= T->y0 &&
+                           ky[yNum] < T->y0 + T->ty && (kz[0] >> 5) >= T->w0 && (kz[zNum] >> 5) < T->w0 + T->tw;
+        unsigned any = 0u;
+        if (tiled) {
+#pragma unroll
+            for (int xi = 0; xi < kAxisMax; ++xi) {
+                if (xi > xNum) continue;
+#pragma unroll
+                for (int yi = 0; yi < kAxisMax; ++yi) {
+                    if (yi > yNum) continue;
+                    const int col = ((kx[xi] - T->x0) * T->ty + (ky[yi] - T->y0)) * T->tw - T->w0;
+#pragma unroll
+                    for (int zi = 0; zi < kAxisMax; ++zi)
+                        if (zi <= zNum) any |= tile_words[col + (kz[zi] >> 5)] >> (kz[zi] & 31);
+                }
+            }
+            return (any & 1u) != 0;
+        }
+        for (int xi = 0; xi <= xNum; ++xi)
+            for (int yi = 0; yi <= yNum; ++yi)
+                for (int zi = 0; zi <= zNum; ++zi) any |= grid_bits_at(g, kx[xi], ky[yi], kz[zi]) >> 1;  // unknown | occupied
+        return any != 0;
+    }
+    // a collision box of more than 3 map cells per axis: the reference's walk as written
+    for (int xi = 0; xi <= xNum && !hit; ++xi) {
+        const float qx = (float)(xmin + xi * map_res);
+        const bool x_out = (qx < g.bmin[0]) || (qx > g.bmax[0]);
+        const int kx = (int)floor(rf * (double)qx) - g.key0[0];
+        for (int yi = 0; yi <= yNum && !hit; ++yi) {
+            const float qy = (float)(ymin + yi * map_res);
+            const bool y_out = (qy < g.bmin[1]) || (qy > g.bmax[1]);
+            const int ky = (int)floor(rf * (double)qy) - g.key0[1];
+            for (int zi = 0; zi <= zNum; ++zi) {
+                const float qz = (float)(zmin + zi * map_res);
+                if (x_out || y_out || (qz < g.bmin[2]) || (qz > g.bmax[2])) { hit = true; break; }
+                const int kz = (int)floor(rf * (double)qz) - g.key0[2];
+                if ((grid_bits_at(g, kx, ky, kz) >> 1) != 0) { hit = true; break; }  // outside -> 7 -> collides
+            }
+        }
+    }
+    return hit;
+}
 
 __global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A) {
     extern __shared__ __align__(16) uint32_t tile_words[];
@@ -117,10 +211,10 @@ __global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A)
         bool any = s_min[0] != 0x7fffffff;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const double lo = (double)ord2f(s_min[a]) - A.box[a] / 2;
-            const double hi = (double)ord2f(s_max[a]) + A.box[a] / 2 + A.map_res;
-            double l = floor(A.rf * lo) - g.key0[a] - 1;
-            double h = floor(A.rf * hi) - g.key0[a] + 1;
+            const double lo = (double)ord2f(s_min[a]) - A.sweep.box[a] / 2;
+            const double hi = (double)ord2f(s_max[a]) + A.sweep.box[a] / 2 + A.sweep.map_res;
+            double l = floor(A.sweep.rf * lo) - g.key0[a] - 1;
+            double h = floor(A.sweep.rf * hi) - g.key0[a] + 1;
             l = fmax(l, 0.0);
             h = fmin(h, (double)(dims[a] - 1));
             lo_i[a] = (int)l;
@@ -156,39 +250,7 @@ __global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A)
             double p[3];
             poly_pos(cf, deg, t, p);
             const float fx = (float)p[0], fy = (float)p[1], fz = (float)p[2];  // pose2Octomap
-            // PO.cpp:548-555
-            const double xmin = fx - A.box[0] / 2, xmax = fx + A.box[0] / 2;
-            const double ymin = fy - A.box[1] / 2, ymax = fy + A.box[1] / 2;
-            const double zmin = fz - A.box[2] / 2, zmax = fz + A.box[2] / 2;
-            const int xNum = (int)((xmax - xmin) / A.map_res);
-            const int yNum = (int)((ymax - ymin) / A.map_res);
-            const int zNum = (int)((zmax - zmin) / A.map_res);
-            bool hit = false;
-            for (int xi = 0; xi <= xNum && !hit; ++xi) {
-                const float qx = (float)(xmin + xi * A.map_res);
-                const bool x_out = (qx < g.bmin[0]) || (qx > g.bmax[0]);
-                const int kx = (int)floor(A.rf * (double)qx) - g.key0[0];
-                for (int yi = 0; yi <= yNum && !hit; ++yi) {
-                    const float qy = (float)(ymin + yi * A.map_res);
-                    const bool y_out = (qy < g.bmin[1]) || (qy > g.bmax[1]);
-                    const int ky = (int)floor(A.rf * (double)qy) - g.key0[1];
-                    for (int zi = 0; zi <= zNum; ++zi) {
-                        const float qz = (float)(zmin + zi * A.map_res);
-                        // PO.cpp:572-577 metric bounds, then OcTree::search == NULL -> occupied
-                        if (x_out || y_out || (qz < g.bmin[2]) || (qz > g.bmax[2])) { hit = true; break; }
-                        const int kz = (int)floor(A.rf * (double)qz) - g.key0[2];
-                        if (kx < 0 || ky < 0 || kz < 0 || kx >= g.nx || ky >= g.ny || kz >= g.nz) { hit = true; break; }
-                        unsigned bit;
-                        const int lx = kx - T.x0, ly = ky - T.y0, lw = (kz >> 5) - T.w0;
-                        if (T.in_lds && lx >= 0 && ly >= 0 && lw >= 0 && lx < T.tx && ly < T.ty && lw < T.tw) {
-                            bit = (tile_words[(lx * T.ty + ly) * T.tw + lw] >> (kz & 31)) & 1u;
-                        } else {
-                            bit = (grid_bits_at(g, kx, ky, kz) >> 1) != 0;  // unknown | occupied
-                        }
-                        if (bit) { hit = true; break; }
-                    }
-                }
-            }
+            const bool hit = box_sweep(g, A.sweep, fx, fy, fz, &T, tile_words);
             if (hit) {
                 if (k < my_first) my_first = k;
                 ++my_count;
@@ -211,34 +273,11 @@ __global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A)
 // ---- box sweep at given sample positions (polyTrajOctomap::checkCollision per pose) -------------
 // One thread per pose; lookups go to the packed planes (L2).  Serves the reference's
 // checkCollisionTraj(trajectory, ...) signatures, where the samples already exist (PO.cpp:619-656).
-__global__ void k_box_points(GridView g, int64_t M, const double* __restrict__ pts, double bx, double by, double bz,
-                             double map_res, double rf, uint8_t* __restrict__ out) {
+__global__ void k_box_points(GridView g, int64_t M, const double* __restrict__ pts, SweepConst C, uint8_t* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const float fx = (float)pts[3 * i], fy = (float)pts[3 * i + 1], fz = (float)pts[3 * i + 2];  // pose2Octomap
-    const double xmin = fx - bx / 2, xmax = fx + bx / 2;
-    const double ymin = fy - by / 2, ymax = fy + by / 2;
-    const double zmin = fz - bz / 2, zmax = fz + bz / 2;
-    const int xNum = (int)((xmax - xmin) / map_res);
-    const int yNum = (int)((ymax - ymin) / map_res);
-    const int zNum = (int)((zmax - zmin) / map_res);
-    bool hit = false;
-    for (int xi = 0; xi <= xNum && !hit; ++xi) {
-        const float qx = (float)(xmin + xi * map_res);
-        const bool x_out = (qx < g.bmin[0]) || (qx > g.bmax[0]);
-        const int kx = (int)floor(rf * (double)qx) - g.key0[0];
-        for (int yi = 0; yi <= yNum && !hit; ++yi) {
-            const float qy = (float)(ymin + yi * map_res);
-            const bool y_out = (qy < g.bmin[1]) || (qy > g.bmax[1]);
-            const int ky = (int)floor(rf * (double)qy) - g.key0[1];
-            for (int zi = 0; zi <= zNum; ++zi) {
-                const float qz = (float)(zmin + zi * map_res);
-                if (x_out || y_out || (qz < g.bmin[2]) || (qz > g.bmax[2])) { hit = true; break; }
-                const int kz = (int)floor(rf * (double)qz) - g.key0[2];
-                if ((grid_bits_at(g, kx, ky, kz) >> 1) != 0) { hit = true; break; }  // outside -> 7 -> collides
-            }
-        }
-    }
+    const bool hit = box_sweep(g, C, fx, fy, fz, nullptr, nullptr);
     out[i] = (uint8_t)hit;
 }
 
@@ -296,9 +335,7 @@ int launch_corridor_check(hipStream_t s, const GridView& g, int S, int deg, cons
     CorridorArgs A{};
     A.S = S; A.deg = deg;
     A.coeffs = coeffs; A.n_samp = n_samp; A.delT = delT;
-    A.box[0] = box[0]; A.box[1] = box[1]; A.box[2] = box[2];
-    A.map_res = map_res;
-    A.rf = 1.0 / g.res;
+    A.sweep = SweepConst{{box[0], box[1], box[2]}, map_res, 1.0 / g.res};
     A.out_flag = out_flag; A.out_first = out_first; A.out_count = out_count;
     const int tile_bytes = 32 * 1024;
     A.tile_words_cap = tile_bytes / 4;
@@ -310,8 +347,8 @@ int launch_box_points(hipStream_t s, const GridView& g, int64_t M, const double*
                       double map_res, uint8_t* out) {
     if (M <= 0) return hipSuccess;
     const int block = 256;
-    hipLaunchKernelGGL(k_box_points, dim3((unsigned)((M + block - 1) / block)), dim3(block), 0, s, g, M, pts, box[0],
-                       box[1], box[2], map_res, 1.0 / g.res, out);
+    hipLaunchKernelGGL(k_box_points, dim3((unsigned)((M + block - 1) / block)), dim3(block), 0, s, g, M, pts,
+                       SweepConst{{box[0], box[1], box[2]}, map_res, 1.0 / g.res}, out);
     return (int)hipGetLastError();
 }
 
