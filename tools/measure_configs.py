@@ -111,6 +111,32 @@ print(json.dumps({"config": "3: 4096 segments x 10k samples, box [0.4,0.4,0.2] s
                   "samples_per_s": samples / dt, "lattice_lookups_per_s": samples * 18 / dt, "colliding_segments": int(flag.sum())}), flush=True)
 v.close()
 
+# config 3 with real coefficients: batched min-snap QP (586 paths x 7 segments = 4102 segments), corridor 0.5, then the checker
+rng = np.random.default_rng(5)
+Tn, Wn = 586, 8
+wp = np.zeros((Tn, Wn, 3))
+wp[:, 0] = rng.uniform(-8, 8, size=(Tn, 3)) * [1, 1, 0.1] + [0, 0, 1.5]
+for i in range(1, Wn):
+    step = rng.normal(size=(Tn, 3)) * [1, 1, 0.1]
+    step *= (rng.uniform(1.0, 3.0, size=(Tn, 1)) / np.linalg.norm(step, axis=1, keepdims=True))
+    wp[:, i] = wp[:, i - 1] + step
+d_wp, d_cor = T(wp), T(np.full((Tn, Wn - 1), 0.5))
+v = Vigo(0)
+v.set_grid(T(world3.voxels), world3.origin, world3.res)
+dt_free = timeit(lambda: v.minsnap(d_wp), 20, 2)
+dt_cor = timeit(lambda: v.minsnap(d_wp, d_cor), 20, 2)
+co, kn, st = v.minsnap(d_wp, d_cor)
+dur = (kn[:, 1:] - kn[:, :-1]).reshape(-1)
+ns3 = torch.full((Tn * (Wn - 1),), 10000, dtype=torch.int32, device=dev)
+dl3 = (dur / 10000.0).contiguous()
+seg = co.reshape(Tn * (Wn - 1), 3, 8)
+dt_chk = timeit(lambda: v.corridor_check(seg, ns3, dl3, box, 0.2), 10, 2)
+print(json.dumps({"config": "3 (real coefficients): vigo_minsnap 586 paths x 8 waypoints -> 4102 segments x 10k samples",
+                  "minsnap_ms_no_corridor": dt_free * 1e3, "minsnap_ms_corridor_0.5": dt_cor * 1e3, "paths_per_s_corridor": Tn / dt_cor,
+                  "solved": int((st == 0).sum()), "infeasible": int((st == -2).sum()), "checker_ms": dt_chk * 1e3,
+                  "samples_per_s": Tn * (Wn - 1) * 10000 / dt_chk}), flush=True)
+v.close()
+
 # config 4 shard: 8192 x 64 control points, 512^3 grid
 w512 = synth.make_box_world(synth.SEED_BASE + 4, n=512, n_boxes=800, centre_range=24.0)
 solve_cfg("4 shard: 8192x64, 512^3, 50 it (one of 8 GPUs)", w512, 8192, 64, PREC_F64, reps=5)
