@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and other-arithmetic-mode side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="rehearsal of the N > 1 rank logic on a one-GPU box: every rank uses cuda:0 and the collectives "
+                         "go over gloo (host-staged); timings are meaningless, the printed line is marked")
     return ap.parse_args()
 
 
@@ -145,10 +148,28 @@ def main():
     import torch.distributed as dist
     from trajectory_planner_amd.vigo import PREC_F32, PREC_F64, Vigo, default_params
 
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+
+    def bcast(t):
+        if args.rehearse_on_one_gpu:      # gloo: stage through the host
+            h = t.cpu()
+            dist.broadcast(h, src=0)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=0)
+
+    def max_over_ranks(x):
+        te = torch.tensor([x], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        return float(te.item())
 
     world, batch, wname = workload(args, rank, world_size)
     P = default_params()
@@ -169,7 +190,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         t_b0 = time.perf_counter()
-        dist.broadcast(packed, src=0)
+        bcast(packed)
         torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - t_b0) * 1e3
     v.set_grid_packed(packed, dims, world.origin, world.res)
@@ -208,9 +229,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world_size > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        elapsed = max_over_ranks(elapsed)
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
 
@@ -288,7 +307,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "f64",
             "arithmetic": args.precision,
-            "data": "synthetic (seeded straight paths + box world, SURVEY.md §8d; no dataset exists for this path)",
+            "data": "synthetic (seeded straight paths + box world, SURVEY.md §8d; no dataset exists for this path)"
+                    + (" — REHEARSAL of the rank logic on one GPU, not a measurement" if args.rehearse_on_one_gpu else ""),
             "config": {"workload": wname, "trajs_per_gpu": B, "ctrl_pts": N, "lbfgs_iters": args.iters,
                        "mem_size": int(P.mem_size), "g_epsilon": float(P.g_epsilon), "grid": list(dims),
                        "guide_pairs_per_gpu": int(gpv.shape[0]), "sharding": f"batch-dp{world_size}, no data-path collective",
