@@ -109,8 +109,8 @@ __host__ __device__ inline Layout make_layout(int K, int cont) {
     auto take = [&](int cnt) { int at = o; o += (cnt + 1) & ~1; return at; };
     L.knots = take(K + 1);
     L.wpl = take((K + 1) * 3);
-    L.Q = take(L.n * L.n);
-    L.M = take(L.n * L.me);
+    L.Q = take(L.n * (L.me + L.n));   // W = [A_eq' | Q'] row by row, see the kernel
+    L.M = L.Q;
     L.beq = take(L.me * 3);
     L.x0 = take(L.n * 3);
     L.PZ = take(L.n * L.nf);
@@ -148,8 +148,15 @@ __global__ void __launch_bounds__(kLanes) k_minsnap(MinsnapArgs A) {
     const Layout L = make_layout(K, A.cont);
     const int n = L.n, me = L.me, nf = L.nf;
     double* knots = S + L.knots;
-    double* Q = S + L.Q;
-    double* M = S + L.M;      // A_eq' (n x me), row-major [i * me + r]
+    // One work matrix W, n rows of ld = me + n doubles: columns [0, me) hold A_eq' (-> R), columns
+    // [me, me + n) hold Q TRANSPOSED (W(i, me + r) = Q(r, i)).  A Householder step then applies the
+    // same "column -= 2 v (v'column) / v'v" to every column of W — one uniform task per lane, and
+    // consecutive lanes hit consecutive LDS words (row-major Q at a 56-double stride put 64 rows on
+    // two banks).
+    double* Wm = S + L.Q;
+    const int ld = me + n;
+#define MAT(i, c) Wm[(i) * ld + (c)]
+#define QAT(r, c) Wm[(c) * ld + me + (r)]
     double* beq = S + L.beq;  // [r * 3 + axis]
     double* x0 = S + L.x0;    // [i * 3 + axis]
     double* PZ = S + L.PZ;    // [i * nf + k]
@@ -191,8 +198,10 @@ __global__ void __launch_bounds__(kLanes) k_minsnap(MinsnapArgs A) {
         s_status = 0;
         s_nb = 0;
     }
-    for (int i = lane; i < n * n; i += kLanes) Q[i] = (i / n == i % n) ? 1.0 : 0.0;
-    for (int i = lane; i < n * me; i += kLanes) M[i] = 0.0;
+    for (int idx = lane; idx < n * ld; idx += kLanes) {
+        const int i = idx / ld, c = idx % ld;
+        Wm[idx] = (c >= me && c - me == i) ? 1.0 : 0.0;
+    }
     __syncthreads();
 
     // ---- equality rows (PS.cpp:314-560 order), one lane per row, written as columns of M ----
@@ -200,7 +209,7 @@ __global__ void __launch_bounds__(kLanes) k_minsnap(MinsnapArgs A) {
         const int r = lane;
         const int last = (K - 1) * D;
         double b[3] = {0.0, 0.0, 0.0};
-        auto put = [&](int col, double v) { M[col * me + r] += v; };
+        auto put = [&](int col, double v) { MAT(col, r) += v; };
         int row = r;
         bool done = false;
         // position: start, end, K-1 interior waypoints, K-1 continuity
@@ -245,10 +254,10 @@ __global__ void __launch_bounds__(kLanes) k_minsnap(MinsnapArgs A) {
         }
         // unit infinity norm per row (the continuity rows carry dt^order factors)
         double mx = 0.0;
-        for (int i = 0; i < n; ++i) mx = fmax(mx, fabs(M[i * me + r]));
+        for (int i = 0; i < n; ++i) mx = fmax(mx, fabs(MAT(i, r)));
         if (!(mx > 0)) s_status = -1;
         else {
-            for (int i = 0; i < n; ++i) M[i * me + r] /= mx;
+            for (int i = 0; i < n; ++i) MAT(i, r) /= mx;
             for (int a = 0; a < 3; ++a) beq[r * 3 + a] = b[a] / mx;
         }
     }
@@ -258,7 +267,7 @@ __global__ void __launch_bounds__(kLanes) k_minsnap(MinsnapArgs A) {
     for (int j = 0; j < me && s_status == 0; ++j) {
         double part = 0.0;
         for (int i = j + lane; i < n; i += kLanes) {
-            const double a = M[i * me + j];
+            const double a = MAT(i, j);
             vbuf[i] = a;
             part += a * a;
         }
@@ -274,22 +283,17 @@ __global__ void __launch_bounds__(kLanes) k_minsnap(MinsnapArgs A) {
         for (int i = j + lane; i < n; i += kLanes) part += vbuf[i] * vbuf[i];
         const double vv = wave_sum(part);
         if (vv > 0) {
-            // tasks: columns j..me-1 of M, rows 0..n-1 of Q
-            const int ntask = (me - j) + n;
-            for (int task = lane; task < ntask; task += kLanes) {
-                if (task < me - j) {
-                    const int c = j + task;
-                    double s = 0.0;
-                    for (int i = j; i < n; ++i) s += vbuf[i] * M[i * me + c];
-                    s *= 2.0 / vv;
-                    for (int i = j; i < n; ++i) M[i * me + c] -= s * vbuf[i];
-                } else {
-                    const int row = task - (me - j);
-                    double s = 0.0;
-                    for (int i = j; i < n; ++i) s += Q[row * n + i] * vbuf[i];
-                    s *= 2.0 / vv;
-                    for (int i = j; i < n; ++i) Q[row * n + i] -= s * vbuf[i];
-                }
+            // tasks: columns j .. me + n - 1 of W, all alike
+            const double* __restrict__ vb = vbuf;
+            const double scale = 2.0 / vv;
+            for (int c = j + lane; c < ld; c += kLanes) {
+                double* __restrict__ col = Wm + c;
+                double s = 0.0;
+#pragma unroll 8
+                for (int i = j; i < n; ++i) s += vb[i] * col[i * ld];
+                s *= scale;
+#pragma unroll 8
+                for (int i = j; i < n; ++i) col[i * ld] -= s * vb[i];
             }
         }
         __syncthreads();
@@ -300,19 +304,21 @@ __global__ void __launch_bounds__(kLanes) k_minsnap(MinsnapArgs A) {
     }
 
     // ---- particular solution x0 = Y R^-T beq (per axis) ----
-    if (lane < 3) {
-        const int a = lane;
-        for (int i = 0; i < me; ++i) {
-            double s = beq[i * 3 + a];
-            for (int k = 0; k < i; ++k) s -= M[k * me + i] * beq[k * 3 + a];
-            beq[i * 3 + a] = s / M[i * me + i];   // y overwrites beq
+    // R'y = beq by column-oriented forward substitution: y_i is final once rows < i have been
+    // eliminated; all lanes then remove its contribution from the rows below (y overwrites beq)
+    for (int i = 0; i < me; ++i) {
+        if (lane < 3) beq[i * 3 + lane] /= MAT(i, i);
+        __syncthreads();
+        for (int idx = lane; idx < (me - i - 1) * 3; idx += kLanes) {
+            const int r = i + 1 + idx / 3, a = idx % 3;
+            beq[r * 3 + a] -= MAT(i, r) * beq[i * 3 + a];
         }
+        __syncthreads();
     }
-    __syncthreads();
     for (int idx = lane; idx < n * 3; idx += kLanes) {
         const int i = idx / 3, a = idx % 3;
         double s = 0.0;
-        for (int k = 0; k < me; ++k) s += Q[i * n + k] * beq[k * 3 + a];
+        for (int k = 0; k < me; ++k) s += QAT(i, k) * beq[k * 3 + a];
         x0[idx] = s;
     }
     __syncthreads();
@@ -320,17 +326,17 @@ __global__ void __launch_bounds__(kLanes) k_minsnap(MinsnapArgs A) {
     if (nf > 0) {
         // ---- reduced problem: PZ = P Z, H = Z'PZ, c = Z'(P x0) ----
         for (int idx = lane; idx < n * nf; idx += kLanes) {
-            const int i = idx / nf, k = idx % nf;
+            const int k = idx / n, i = idx % n;   // i fastest: conflict-free reads of Qt
             const int seg = i / D, di = i % D;
             double s = 0.0;
-            for (int dj = A.diff; dj < D; ++dj) s += snap_coef(di, dj, A.diff) * Q[(seg * D + dj) * n + me + k];
-            PZ[idx] = s;
+            for (int dj = A.diff; dj < D; ++dj) s += snap_coef(di, dj, A.diff) * QAT(seg * D + dj, me + k);
+            PZ[i * nf + k] = s;
         }
         __syncthreads();
         for (int idx = lane; idx < nf * nf; idx += kLanes) {
             const int a = idx / nf, b = idx % nf;
             double s = 0.0;
-            for (int i = 0; i < n; ++i) s += Q[i * n + me + a] * PZ[i * nf + b];
+            for (int i = 0; i < n; ++i) s += QAT(i, me + a) * PZ[i * nf + b];
             H[idx] = s;
         }
         for (int idx = lane; idx < nf * 3; idx += kLanes) {
@@ -346,7 +352,23 @@ __global__ void __launch_bounds__(kLanes) k_minsnap(MinsnapArgs A) {
             Hinv[idx] = 0.5 * (H[a * nf + b] + H[b * nf + a]);
         }
         __syncthreads();
-        if (lane == 0 && !chol_serial(Hinv, nf, nf)) s_status = -1;   // Hinv holds L for now
+        // right-looking Cholesky across the lanes (Hinv holds L for now): column j is scaled, then
+        // every lane updates its share of the trailing triangle
+        for (int j = 0; j < nf && s_status == 0; ++j) {
+            const double djj = Hinv[j * nf + j];
+            if (!(djj > 0)) { if (lane == 0) s_status = -1; }
+            const double dj = sqrt(djj);
+            __syncthreads();
+            if (s_status != 0) break;
+            for (int i = j + lane; i < nf; i += kLanes) Hinv[i * nf + j] = (i == j) ? dj : Hinv[i * nf + j] / dj;
+            __syncthreads();
+            const int rem = nf - j - 1;
+            for (int idx = lane; idx < rem * rem; idx += kLanes) {
+                const int i = j + 1 + idx / rem, k = j + 1 + idx % rem;
+                if (k <= i) Hinv[i * nf + k] -= Hinv[i * nf + j] * Hinv[k * nf + j];
+            }
+            __syncthreads();
+        }
         __syncthreads();
         if (s_status != 0) {
             if (lane == 0) A.out_status[t] = s_status;
@@ -410,14 +432,14 @@ __global__ void __launch_bounds__(kLanes) k_minsnap(MinsnapArgs A) {
                 const int b = k >> 1, seg = boxSeg[b];
                 const double tt = boxT[b];
                 double s = 0.0, pw = 1.0;
-                for (int d = 0; d < D; ++d) { s += pw * Q[(seg * D + d) * n + me + i]; pw *= tt; }
+                for (int d = 0; d < D; ++d) { s += pw * QAT(seg * D + d, me + i); pw *= tt; }
                 return (k & 1) ? -s : s;
             };
             // xcur <- x0 + Z w (normalised-time coefficients of this axis)
             auto refresh_xcur = [&]() {
                 for (int i = lane; i < n; i += kLanes) {
                     double s = 0.0;
-                    for (int k = 0; k < nf; ++k) s += Q[i * n + me + k] * w[k];
+                    for (int k = 0; k < nf; ++k) s += QAT(i, me + k) * w[k];
                     xcur[i] = x0[i * 3 + axis] + s;
                 }
             };
@@ -564,6 +586,9 @@ __global__ void __launch_bounds__(kLanes) k_minsnap(MinsnapArgs A) {
     for (int i = lane; i < W; i += kLanes) A.out_knots[(size_t)t * W + i] = knots[i];
     if (lane == 0) A.out_status[t] = 0;
 }
+
+#undef QAT
+#undef MAT
 
 }  // namespace
 
