@@ -285,3 +285,51 @@ def test_baseline_sizes_in_full(vigo_handle, name, n, n_boxes, centre, B, N, sta
     assert (rel <= TOL).mean() >= 0.995 and np.median(rel) < 1e-8
     # fixed boundary control points never move (BT.cpp:690-691)
     assert np.array_equal(g["ctrl"][:, :3], b.ctrl[:, :3]) and np.array_equal(g["ctrl"][:, -3:], b.ctrl[:, -3:])
+
+
+def test_parameter_variations_stay_bit_exact(vigo_handle, small_world):
+    """Paths of the kernel the default batch does not reach: more obstacles than the LDS cache holds (20 > 16:
+    the rest is read from HBM/L2), three or more guide pairs on a control point (beyond the two kept in
+    registers), plan_in_z with the height term and its reproduced quirks, an unknown-space factor != 1,
+    per-trajectory weights as the rebound loop produces them, a short history and early convergence."""
+    v = vigo_handle
+    rng = np.random.default_rng(77)
+    P = default_params()
+    P.max_iterations = 40
+    P.mem_size = 5
+    P.plan_in_z = 1
+    P.uncertain_factor = 1.7
+    P.dthresh = 0.6
+    P.dist_thresh_dynamic = 0.7
+    P.g_epsilon = 0.05
+    v.set_params(P)
+    b = synth.make_bspline_batch(small_world, 96, 32, 321, start_range=3.0, n_obs=20, guide2_prob=0.9)
+    # pile extra guide pairs onto the points that already have two (CSR rebuilt)
+    cnt = np.diff(b.guide_off)
+    new_pv, new_unk, new_off = [], [], [0]
+    for i, c in enumerate(cnt):
+        pv = b.guide_pv[b.guide_off[i]:b.guide_off[i + 1]]
+        unk = b.guide_unk[b.guide_off[i]:b.guide_off[i + 1]]
+        if c == 2:
+            extra = pv[[0, 1, 0]] + rng.normal(0, 0.05, size=(3, 6)) * [1, 1, 1, 0, 0, 0]
+            pv = np.concatenate([pv, extra])
+            unk = np.concatenate([unk, [1, 0, 1]]).astype(np.uint8)
+        new_pv.append(pv)
+        new_unk.append(unk)
+        new_off.append(new_off[-1] + len(pv))
+    b2 = synth.Batch(b.ctrl + rng.normal(0, 0.02, size=b.ctrl.shape) * [0, 0, 1], np.array(new_off, dtype=np.int32), np.concatenate(new_pv),
+                     np.concatenate(new_unk).astype(np.uint8), b.obs_off, b.obs)
+    assert np.diff(b2.guide_off).max() >= 5 and np.diff(b2.obs_off).max() == 20
+    w = np.ones((b2.B, 4)) * rng.choice([1.0, 2.0, 4.0, 8.0], size=(b2.B, 4))
+    d = batch_to_dev(b2, v.device, w)
+    r = v.optimize(**d)
+    g = {k: getattr(r, k).cpu().numpy() for k in ("ctrl", "x", "status", "fx", "iters", "evals")}
+    with emulation(32):
+        e = ol.optimize_batch(P, b2, w)
+    for k in ("status", "iters", "evals", "x", "ctrl", "fx"):
+        assert np.array_equal(g[k], e[k], equal_nan=True), f"{k} differs from the emulation-mode oracle"
+    cost, grad, terms = v.cost_grad(**d)
+    with emulation(32):
+        ce, ge, te = ol.cost_grad_batch(P, b2, w)
+    assert np.array_equal(cost.cpu().numpy(), ce) and np.array_equal(grad.cpu().numpy(), ge) and np.array_equal(terms.cpu().numpy(), te)
+    assert (terms.cpu().numpy()[:, 3] > 0).any() and len(np.unique(g["status"])) >= 2
