@@ -20,6 +20,7 @@
 
 #include <memory>
 #include <utility>
+#include <string>
 #include <vector>
 
 const int bsplineDegree = 3;
@@ -106,6 +107,13 @@ public:
 
     /* the lbfgs_evaluate_t seam (BT.h:118-119) on the device: cost and gradient of x */
     double costFunction(const double* x, double* grad, const int n);
+    static double solverCostFunction(void* func_data, const double* x, double* grad, const int n);   // BT.h:118
+    /* the four terms on their own (BT.h:120-123); gradient is 3 x N with the fixed end columns left zero */
+    void getDistanceCost(const Eigen::MatrixXd& controlPoints, double& cost, Eigen::MatrixXd& gradient);
+    void getSmoothnessCost(const Eigen::MatrixXd& controlPoints, double& cost, Eigen::MatrixXd& gradient);
+    void getFeasibilityCost(const Eigen::MatrixXd& controlPoints, double& cost, Eigen::MatrixXd& gradient);
+    void getDynamicObstacleCost(const Eigen::MatrixXd& controlPoints, double& cost, Eigen::MatrixXd& gradient);
+    void writeCurrentTrajInfo(const std::string& filePath, double dt);                               // BT.cpp:1464-1496
 
     void linearFeasibilityReparam();
     double getLinearReparamTime(double t);
@@ -146,6 +154,7 @@ private:
     void reboundStep(Rebound& r, bool hasCollision, bool hasDynamicCollision, bool timedOut);
     bool prepareFitPoints(const nav_msgs::Path& adjustedPath, std::vector<Eigen::Vector3d>& adjustedCurveFitPoints);
     void installControlPoints(const Eigen::MatrixXd& controlPoints, const std::vector<Eigen::Vector3d>& adjustedCurveFitPoints);
+    bool termCost(int term, const Eigen::MatrixXd& controlPoints, double& cost, Eigen::MatrixXd& gradient);
     static void solveBatch(const std::vector<bsplineTraj*>& ps);   // one vigo_optimize for all
     static void gateBatch(const std::vector<bsplineTraj*>& ps, std::vector<uint8_t>& col, std::vector<uint8_t>& dyn);
 };

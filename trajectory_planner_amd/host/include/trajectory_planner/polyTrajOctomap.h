@@ -17,6 +17,7 @@
 #include <trajectory_planner/utils.h>
 
 #include <memory>
+#include <ostream>
 #include <set>
 #include <vector>
 
@@ -44,9 +45,6 @@ private:
     int lastIterations_ = 0;
     bool syncDevice();
     bool sweepPoints(const std::vector<pose>& pts, std::vector<uint8_t>& flags);
-    void insertWaypoint(const std::set<int>& seg);
-    void makePlanAddingWaypoint(std::vector<pose>& trajectory, double delT);
-    void makePlanCorridorConstraint(std::vector<pose>& trajectory, double delT);
     void pwlPlan(std::vector<pose>& trajectory, double delT);
     pose pwlPose(double t);
     pose extPose(double t);
@@ -75,8 +73,14 @@ public:
      * trajectories[i] receives planner i's samples (delT = its sample_delta_time). */
     static std::vector<bool> makePlanBatch(const std::vector<polyTrajOctomap*>& planners, std::vector<std::vector<pose>>& trajectories);
     void makePlan();
-    void makePlan(nav_msgs::Path& trajectory, double delT);
-    void makePlan(std::vector<pose>& trajectory, double delT);
+    void makePlan(nav_msgs::Path& trajectory, double delT = 0.1);
+    void makePlan(std::vector<pose>& trajectory, double delT = 0.1);
+    /* the two planning loops, public in the reference as well (PO.h:100-103) */
+    void makePlanAddingWaypoint(std::vector<pose>& trajectory, double delT);
+    void makePlanCorridorConstraint(std::vector<pose>& trajectory, double delT);
+    void insertWaypoint(const std::set<int>& seg);                     // PO.cpp:178-186
+    /* re-snapshot the map on the next device call (the reference re-fetches /octomap_binary, PO.cpp:133-145) */
+    void updateMap() { mapVersion_ = 0; }
 
     bool checkCollision(const pose& p);                                         // box sweep, PO.cpp:547-568
     bool checkCollisionPoint(const pose& p, bool ignoreUnknown = false);        // PO.cpp:571-595
@@ -85,10 +89,26 @@ public:
 
     geometry_msgs::PoseStamped getPose(double t);                   // PO.cpp:658-677
     double getDuration();                                           // PO.cpp:679-689
+    /* parameter getters the nodes' `cout << polyPlanner` prints (PO.h:118-123) */
+    double getDegree() { return polyDegree_; }
+    double getDiffDegree() { return diffDegree_; }
+    double getContinuityDegree() { return continuityDegree_; }
+    double getDesiredVel() { return desiredVel_; }
+    double getInitialRadius() { return initR_; }
+    double getShrinkFactor() { return fs_; }
     bool isValid() const { return findValidTraj_; }
     int getIterations() const { return lastIterations_; }
     const std::vector<pose>& getPath() const { return path_; }
     void trajMsgConverter(const std::vector<pose>& trajectoryTemp, nav_msgs::Path& trajectory);
 };
+
+/* `cout << polyPlanner` of the demo nodes (src/poly_RRT_node.cpp:68) */
+inline std::ostream& operator<<(std::ostream& os, polyTrajOctomap& planner) {
+    os << "[polyTrajOctomap on MI355X] min-snap + corridor planner: polynomial degree " << planner.getDegree()
+       << ", minimised derivative " << planner.getDiffDegree() << ", continuity up to order " << planner.getContinuityDegree()
+       << ", desired velocity " << planner.getDesiredVel() << " m/s, corridor r0 " << planner.getInitialRadius() << " m x "
+       << planner.getShrinkFactor() << " per shrink";
+    return os;
+}
 }  // namespace trajPlanner
 #endif

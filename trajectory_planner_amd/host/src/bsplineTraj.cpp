@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <fstream>
 #include <cstring>
 #include <iostream>
 #include <set>
@@ -732,6 +733,78 @@ double bsplineTraj::costFunction(const double* x, double* grad, const int n) {
     double cost = 0;
     if (hipDeviceSynchronize() != hipSuccess || !dCost.download(&cost, 8) || !dGrad.download(grad, (size_t)n * 8)) return std::nan("");
     return cost;
+}
+
+// BT.cpp:796-800: the lbfgs_evaluate_t-shaped entry (instance pointer first)
+double bsplineTraj::solverCostFunction(void* func_data, const double* x, double* grad, const int n) {
+    return reinterpret_cast<bsplineTraj*>(func_data)->costFunction(x, grad, n);
+}
+
+// One cost term and its gradient for the given control points, evaluated by the device kernel with a
+// unit weight on that term (vigo_cost_grad's per-trajectory weights).  Columns of the three fixed control
+// points at either end stay zero: the reference computes and then discards them (BT.cpp:819).
+bool bsplineTraj::termCost(int term, const Eigen::MatrixXd& controlPoints, double& cost, Eigen::MatrixXd& gradient) {
+    cost = 0;
+    const int N = controlPoints.cols();
+    gradient.resize(3, N);
+    if (N < 7 || N > VIGO_MAX_CTRL_POINTS || (int)optData_.guidePoints.size() < N || !syncDevice()) return false;
+    std::vector<double> gpv, obs, w(4, 0.0);
+    w[term] = 1.0;
+    std::vector<int32_t> goff{0};
+    for (int i = 0; i < N; ++i) {
+        for (size_t j = 0; j < optData_.guidePoints[i].size(); ++j) {
+            for (int q = 0; q < 3; ++q) gpv.push_back(optData_.guidePoints[i][j](q));
+            for (int q = 0; q < 3; ++q) gpv.push_back(optData_.guideDirections[i][j](q));
+        }
+        goff.push_back((int32_t)(gpv.size() / 6));
+    }
+    for (size_t j = 0; j < optData_.dynamicObstaclesPos.size(); ++j) {
+        for (int q = 0; q < 3; ++q) obs.push_back(optData_.dynamicObstaclesPos[j](q));
+        for (int q = 0; q < 3; ++q) obs.push_back(optData_.dynamicObstaclesVel[j](q));
+        for (int q = 0; q < 3; ++q) obs.push_back(optData_.dynamicObstaclesSize[j](q));
+    }
+    const size_t G = gpv.size() / 6;
+    const int n = 3 * (N - 2 * bsplineDegree);
+    DevBuf dCtrl, dGoff, dGpv, dGunk, dObs, dW, dCost, dGrad;
+    if (!dCtrl.upload(controlPoints.data(), 3 * N * 8) || !dGoff.upload(goff.data(), goff.size() * 4) || !dGpv.upload(gpv.data(), gpv.size() * 8) ||
+        !dGunk.alloc(G) || !dObs.upload(obs.data(), obs.size() * 8) || !dW.upload(w.data(), 32) || !dCost.alloc(8) || !dGrad.alloc((size_t)n * 8))
+        return false;
+    if (G && vigo_guides_unknown(dev_, (int64_t)G, (const double*)dGpv.p, (uint8_t*)dGunk.p) != VIGO_OK) return false;
+    if (vigo_cost_grad(dev_, 1, N, (const double*)dCtrl.p, (const int32_t*)dGoff.p, G ? (const double*)dGpv.p : nullptr,
+                       G ? (const uint8_t*)dGunk.p : nullptr, nullptr, obs.empty() ? nullptr : (const double*)dObs.p, (int)(obs.size() / 9),
+                       (const double*)dW.p, (double*)dCost.p, (double*)dGrad.p, nullptr) != VIGO_OK)
+        return false;
+    std::vector<double> g(n);
+    if (hipDeviceSynchronize() != hipSuccess || !dCost.download(&cost, 8) || !dGrad.download(g.data(), (size_t)n * 8)) return false;
+    std::memcpy(gradient.data() + 3 * bsplineDegree, g.data(), (size_t)n * 8);
+    return true;
+}
+// BT.cpp:823-932, :934-950, :952-999, :1001-1064
+void bsplineTraj::getDistanceCost(const Eigen::MatrixXd& controlPoints, double& cost, Eigen::MatrixXd& gradient) { termCost(0, controlPoints, cost, gradient); }
+void bsplineTraj::getSmoothnessCost(const Eigen::MatrixXd& controlPoints, double& cost, Eigen::MatrixXd& gradient) { termCost(1, controlPoints, cost, gradient); }
+void bsplineTraj::getFeasibilityCost(const Eigen::MatrixXd& controlPoints, double& cost, Eigen::MatrixXd& gradient) { termCost(2, controlPoints, cost, gradient); }
+void bsplineTraj::getDynamicObstacleCost(const Eigen::MatrixXd& controlPoints, double& cost, Eigen::MatrixXd& gradient) { termCost(3, controlPoints, cost, gradient); }
+
+// BT.cpp:1464-1496: velocity / acceleration samples of the current trajectory as text files, raw and
+// with the linear feasibility re-parameterisation.  (The reference fills acc_adjusted_info.txt from the
+// VELOCITY spline scaled by factor^2, BT.cpp:1488 — reproduced.)
+void bsplineTraj::writeCurrentTrajInfo(const std::string& filePath, double dt) {
+    if (!(dt > 0)) return;
+    std::ofstream velInfo(filePath + "/vel_info.txt"), accInfo(filePath + "/acc_info.txt");
+    std::ofstream velAdj(filePath + "/vel_adjusted_info.txt"), accAdj(filePath + "/acc_adjusted_info.txt");
+    trajPlanner::bspline vel = this->bspline_.getDerivative();
+    trajPlanner::bspline acc = vel.getDerivative();
+    for (double t = 0.0; t <= this->bspline_.getDuration(); t += dt) {
+        const Eigen::Vector3d v = vel.at(t), a = acc.at(t);
+        velInfo << t << " " << v(0) << " " << v(1) << " " << v(2) << "\n";
+        accInfo << t << " " << a(0) << " " << a(1) << " " << a(2) << "\n";
+    }
+    const double f = this->getLinearFactor();
+    for (double t = 0.0; this->getLinearReparamTime(t) <= this->bspline_.getDuration(); t += dt) {
+        const Eigen::Vector3d v = vel.at(this->getLinearReparamTime(t));
+        velAdj << t << " " << v(0) * f << " " << v(1) * f << " " << v(2) * f << "\n";
+        accAdj << t << " " << v(0) * f * f << " " << v(1) * f * f << " " << v(2) * f * f << "\n";
+    }
 }
 
 // BT.h:307-325 / :344-368 through the device gates

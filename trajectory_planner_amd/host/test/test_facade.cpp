@@ -5,6 +5,7 @@
 #include <trajectory_planner/polyTrajOctomap.h>
 
 #include <cmath>
+#include <iostream>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -107,6 +108,17 @@ int main() {
             worst = std::fmax(worst, std::fabs(fd - g[k]) / std::fmax(1.0, std::fabs(g[k])));
         }
         CHECK(std::isfinite(f0) && worst < 1e-4, "costFunction gradient matches central differences");
+        // the four terms on their own add up to the total (unit weights) and so do their gradients
+        double cd, cs, cf, co;
+        Eigen::MatrixXd gd, gs, gf, go;
+        bst.getDistanceCost(c1, cd, gd);
+        bst.getSmoothnessCost(c1, cs, gs);
+        bst.getFeasibilityCost(c1, cf, gf);
+        bst.getDynamicObstacleCost(c1, co, go);
+        double gerr = 0;
+        for (int k = 0; k < n; ++k) gerr = std::fmax(gerr, std::fabs(gd.data()[9 + k] + gs.data()[9 + k] + gf.data()[9 + k] + go.data()[9 + k] - g[k]));
+        CHECK(std::fabs(cd + cs + cf + co - f0) <= 1e-12 * std::fmax(1.0, f0) && gerr <= 1e-12 * std::fmax(1.0, f0) && cs > 0, "getDistance/Smoothness/Feasibility/DynamicObstacleCost sum to costFunction");
+        CHECK(bsplineTraj::solverCostFunction(&bst, x.data(), gp.data(), n) == f0, "solverCostFunction is the lbfgs_evaluate_t-shaped costFunction");
     }
 
     // a goal inside an obstacle is refused (BT.cpp:291-295)
@@ -166,6 +178,7 @@ int main() {
         nh.setParam("map_resolution", 0.2);
         nh.setParam("sample_delta_time", 0.1);
         trajPlanner::polyTrajOctomap poly(nh);
+        std::cout << poly << std::endl;   // src/poly_RRT_node.cpp:68
         poly.setMap(map);
         std::vector<trajPlanner::pose> wp{{-3, 0, 1}, {0, 2.0, 1}, {3, 0, 1}};
         poly.updatePath(wp);
