@@ -67,6 +67,31 @@ for (Bf, Kf) in ((1024, 30), (65536, 30), (8192, 62), (65536, 62)):
 v.close()
 
 w256 = synth.make_box_world(synth.SEED_BASE + 2, n=256, n_boxes=200)
+
+# map kernels and rebound-loop gates at the config-2 shape
+v = Vigo(0)
+vox256 = T(w256.voxels)
+dt = timeit(lambda: v.pack_grid(vox256), 50)
+print(json.dumps({"config": "map: vigo_pack_grid 256^3 byte grid -> 3 bit planes", "ms": dt * 1e3, "GBps_in": 256 ** 3 / dt / 1e9}), flush=True)
+v.set_grid(vox256, w256.origin, w256.res)
+bg = synth.make_bspline_batch(w256, 16384, 32, 99, start_range=8.0, n_obs=2)
+ctrl_g, ooff_g, obs_g = T(bg.ctrl), T(bg.obs_off), T(bg.obs)
+dtg = w256.res / 2.0 / 2.0          # res / maxVel / 2 with maxVel = 2 (src/bspline_node.cpp:230)
+for name, f, unit in (("gate: vigo_traj_collision (hasCollisionTrajectory), 16384 x 32, dt 0.025", lambda: v.traj_collision(ctrl_g, dtg), "trajs_per_s"),
+                      ("gate: vigo_traj_dynamic_collision, 2 obstacles each", lambda: v.traj_dynamic_collision(ctrl_g, dtg, ooff_g, obs_g), "trajs_per_s"),
+                      ("gate: vigo_ctrl_occupancy (findCollisionSeg queries)", lambda: v.ctrl_occupancy(ctrl_g), "trajs_per_s")):
+    f()
+    dt = timeit(f, 30)
+    print(json.dumps({"config": name, "ms": dt * 1e3, unit: 16384 / dt}), flush=True)
+tq = T(np.linspace(0.0, 5.8, 233))
+dt = timeit(lambda: v.bspline_eval(ctrl_g, tq), 30)
+print(json.dumps({"config": "bspline::at batched: 16384 x 32 ctrl pts x 233 times", "ms": dt * 1e3, "evals_per_s": 16384 * 233 / dt}), flush=True)
+qp = T(np.random.default_rng(1).uniform(-12.7, 12.7, size=(1 << 22, 3)))
+dt = timeit(lambda: v.query_points(qp, 0), 30)
+print(json.dumps({"config": "map: vigo_query_points 4 M random points (isInflatedOccupied)", "ms": dt * 1e3, "queries_per_s": (1 << 22) / dt}), flush=True)
+v.close()
+del vox256, bg, ctrl_g, qp
+
 solve_cfg("2: 1024x32, 256^3, 50 it", w256, 1024, 32, PREC_F64)
 solve_cfg("2 (f64_fast mode)", w256, 1024, 32, 2)
 solve_cfg("2 (fp32 mode)", w256, 1024, 32, PREC_F32)
