@@ -10,14 +10,11 @@
 //                 -> R, Q'; back-substitution of every column of Q' gives the least-squares
 //                 operator A+ = R^-1 Q'[:K+2] stored TRANSPOSED, pinvT[j][row], so that lanes
 //                 (rows) read consecutive addresses;
-//   k_bspline_fit one wave per workgroup, lane <-> control point (row of A+): the lane keeps its
-//                 row of A+ in registers for all trajectories of its grid-stride loop, the K+4
-//                 input rows of a trajectory arrive through the scalar cache (wave-uniform
-//                 addresses), output [K+2][3] written coalesced.  Nominal bound HBM,
-//                 (2K + 6) * 24 algorithmic bytes per trajectory; measured 1.7 TB/s (21 % of
-//                 peak) at 65 536 paths x 30 waypoints — each wave walks its paths one at a time,
-//                 so it is bound by the latency of a path's dependent load -> FMA chain, not by
-//                 LDS, VALU or the store pattern (variants of all three measured the same).
+//   k_bspline_fit_mfma  the batch as ONE dense product A+ * [rhs of all paths] on the fp64 matrix
+//                 cores, 5 paths per wave and tile column group (see below); HBM-bound,
+//                 (2K + 6) * 24 algorithmic bytes per path: 4.1 TB/s (51 % of peak) at 65 536
+//                 paths x 30 waypoints, 1.7 TB/s at 62 waypoints;
+//   k_bspline_fit_gen   more than 62 waypoints: VALU kernel, A+ streamed from L2.
 // fp64, explicit fused multiply-adds in index order: deterministic, batch-invariant.
 #include "vigo_internal.hpp"
 
@@ -110,65 +107,59 @@ __device__ __forceinline__ double fit_rhs(const double* __restrict__ points, con
     return conds ? conds[b * 12 + (i - 3 * K)] : 0.0;
 }
 
-// C <= 64: lane <-> control point, its row of A+ in registers (KMAX >= K).  A path's right-hand
-// side is the same for every lane: its addresses are wave-uniform, so the compiler fetches it with
-// scalar loads (s_load_dwordx*, scalar cache) and the FMAs take it as SGPR operands — no LDS
-// staging, no barriers; the lanes' only vector memory traffic is the coalesced 24-byte store.
-template <int KMAX>
-__global__ void __launch_bounds__(64) k_bspline_fit_reg(int B, int K, const double* __restrict__ pinvT,
-                                                        const double* __restrict__ points,
-                                                        const double* __restrict__ conds, double* __restrict__ out) {
-    const int C = K + 2;
-    const int row = threadIdx.x;
-    double P[KMAX], Pc[4];
+// ---- the fit as what it is, a dense product ---------------------------------------------------
+// ctrl[b] = A+ * rhs[b] applies ONE (K+2) x (K+4) operator to every path: out = A+ * [rhs_0 | rhs_1 | ...]
+// with 3 columns (x, y, z) per path — a genuine shared-operand contraction, so it runs on the fp64
+// matrix cores (v_mfma_f64_16x16x4_f64).  One wave takes 5 paths = 15 of the 16 tile columns:
+//   A operand  A+ rows (16 per tile, TILES tiles), one double per lane and k-step, loaded once;
+//   B operand  rhs(j, column): lane (k = lane >> 4, n = lane & 15) loads path n/3, row 4*step + k,
+//              axis n%3 — every byte of the 5 paths is read exactly once, all loads of a group are
+//              independent and in flight together (earlier VALU versions — A+ row in registers, the
+//              rhs through LDS or the scalar cache — walked one path at a time behind its own load
+//              latency and stayed at 1.7 TB/s whatever the LDS, FMA or store variant);
+//   C/D        4 doubles per lane and tile: row (lane >> 4) + 4 r of the tile, column n.
+// K + 4 is padded to a multiple of 4 with zero coefficients.  HBM-bound: (2K + 6) * 24 B per path.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+template <int TILES, int KSTEPS>
+__global__ void __launch_bounds__(256) k_bspline_fit_mfma(int B, int K, const double* __restrict__ pinvT,
+                                                          const double* __restrict__ points,
+                                                          const double* __restrict__ conds, double* __restrict__ out) {
+    const int R = K + 4, C = K + 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, kk = lane >> 4;
+    const int bl = n / 3, ax = n - 3 * bl;       // path within the group, axis
+    double Areg[TILES][KSTEPS];
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) P[j] = (j < K && row < C) ? pinvT[(size_t)j * C + row] : 0.0;
+    for (int t = 0; t < TILES; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) Pc[i] = row < C ? pinvT[(size_t)(K + i) * C + row] : 0.0;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        const double* __restrict__ pt = points + (size_t)b * 3 * K;
-        double ax = 0.0, ay = 0.0, az = 0.0;
-        // rows in chunks of 8 behind ONE uniform branch each: a full chunk's 24 doubles are
-        // contiguous, so the compiler fetches them with a few wide scalar loads issued together;
-        // the last, partial chunk re-reads the final waypoint with zero coefficients (+0 terms)
-#pragma unroll
-        for (int j0 = 0; j0 < KMAX; j0 += 8) {
-            if (j0 + 8 <= K) {
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    if (j0 + jj < KMAX) {
-                        ax = __builtin_fma(P[j0 + jj], pt[3 * (j0 + jj)], ax);
-                        ay = __builtin_fma(P[j0 + jj], pt[3 * (j0 + jj) + 1], ay);
-                        az = __builtin_fma(P[j0 + jj], pt[3 * (j0 + jj) + 2], az);
-                    }
-                }
-            } else if (j0 < K) {
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    if (j0 + jj < KMAX) {
-                        const int jc = j0 + jj < K ? j0 + jj : K - 1;
-                        ax = __builtin_fma(P[j0 + jj], pt[3 * jc], ax);
-                        ay = __builtin_fma(P[j0 + jj], pt[3 * jc + 1], ay);
-                        az = __builtin_fma(P[j0 + jj], pt[3 * jc + 2], az);
-                    }
-                }
-            }
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int row = 16 * t + n, j = 4 * s + kk;
+            Areg[t][s] = (row < C && j < R) ? pinvT[(size_t)j * C + row] : 0.0;
         }
-        if (conds) {
-            const double* __restrict__ cd = conds + (size_t)b * 12;
+    const int groups = (B + 4) / 5;
+    for (int g = blockIdx.x * 4 + wave; g < groups; g += gridDim.x * 4) {
+        const int b = 5 * g + bl;
+        const bool live = (n < 15) && (b < B);
+        double Bv[KSTEPS];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ax = __builtin_fma(Pc[i], cd[3 * i], ax);
-                ay = __builtin_fma(Pc[i], cd[3 * i + 1], ay);
-                az = __builtin_fma(Pc[i], cd[3 * i + 2], az);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { ax = __builtin_fma(Pc[i], 0.0, ax); ay = __builtin_fma(Pc[i], 0.0, ay); az = __builtin_fma(Pc[i], 0.0, az); }   // same sums as with zero conditions
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int j = 4 * s + kk;
+            double v = 0.0;
+            if (live && j < K) v = points[((size_t)b * K + j) * 3 + ax];
+            else if (live && j < R && conds) v = conds[(size_t)b * 12 + (j - K) * 3 + ax];
+            Bv[s] = v;
         }
-        if (row < C) {
-            double* dst = out + ((size_t)b * C + row) * 3;
-            dst[0] = ax; dst[1] = ay; dst[2] = az;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Areg[t][s], Bv[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * t + kk + 4 * r;
+                if (live && row < C) out[((size_t)b * C + row) * 3 + ax] = acc[r];
+            }
         }
     }
 }
@@ -211,10 +202,12 @@ int launch_bspline_fit(hipStream_t s, int B, int K, const double* pinvT, const d
                        double* out) {
     if (B <= 0) return hipSuccess;
     const int grid = B < 4096 ? B : 4096;  // 16 waves per CU worth of workgroups, grid-stride beyond
-    if (K <= 32)
-        hipLaunchKernelGGL((k_bspline_fit_reg<32>), dim3(grid), dim3(64), 0, s, B, K, pinvT, points, conds, out);
-    else if (K + 2 <= 64)  // one lane per control point: C = K + 2 rows must fit the wave
-        hipLaunchKernelGGL((k_bspline_fit_reg<62>), dim3(grid), dim3(64), 0, s, B, K, pinvT, points, conds, out);
+    const int groups = (B + 4) / 5;
+    const int mgrid = groups < 4 * 2048 ? (groups + 3) / 4 : 2048;
+    if (K + 2 <= 32)        // 2 row tiles, K + 4 <= 36 = 9 k-steps
+        hipLaunchKernelGGL((k_bspline_fit_mfma<2, 9>), dim3(mgrid), dim3(256), 0, s, B, K, pinvT, points, conds, out);
+    else if (K + 2 <= 64)   // 4 row tiles, K + 4 <= 68 = 17 k-steps
+        hipLaunchKernelGGL((k_bspline_fit_mfma<4, 17>), dim3(mgrid), dim3(256), 0, s, B, K, pinvT, points, conds, out);
     else
         hipLaunchKernelGGL(k_bspline_fit_gen, dim3(grid), dim3(256), 0, s, B, K, pinvT, points, conds, out);
     return (int)hipGetLastError();
