@@ -13,7 +13,7 @@
 //   k_bspline_fit_mfma  the batch as ONE dense product A+ * [rhs of all paths] on the fp64 matrix
 //                 cores, 5 paths per wave and tile column group (see below); HBM-bound,
 //                 (2K + 6) * 24 algorithmic bytes per path: 4.1 TB/s (51 % of peak) at 65 536
-//                 paths x 30 waypoints, 1.7 TB/s at 62 waypoints;
+//                 paths x 30 waypoints, 2.0 TB/s at 62 waypoints;
 //   k_bspline_fit_gen   more than 62 waypoints: VALU kernel, A+ streamed from L2.
 // fp64, explicit fused multiply-adds in index order: deterministic, batch-invariant.
 #include "vigo_internal.hpp"
@@ -121,7 +121,10 @@ __device__ __forceinline__ double fit_rhs(const double* __restrict__ points, con
 // K + 4 is padded to a multiple of 4 with zero coefficients.  HBM-bound: (2K + 6) * 24 B per path.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-template <int TILES, int KSTEPS>
+// SPLIT waves share a group of paths, each owning TILES of the SPLIT * TILES row tiles (the second
+// wave's right-hand-side loads hit the cache lines the first one fetched): halves the A+ registers
+// per wave at 62 waypoints, doubling the waves in flight.
+template <int TILES, int KSTEPS, int SPLIT>
 __global__ void __launch_bounds__(256) k_bspline_fit_mfma(int B, int K, const double* __restrict__ pinvT,
                                                           const double* __restrict__ points,
                                                           const double* __restrict__ conds, double* __restrict__ out) {
@@ -129,16 +132,18 @@ __global__ void __launch_bounds__(256) k_bspline_fit_mfma(int B, int K, const do
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, kk = lane >> 4;
     const int bl = n / 3, ax = n - 3 * bl;       // path within the group, axis
+    const int tile0 = (wave % SPLIT) * TILES;    // first row tile of this wave
     double Areg[TILES][KSTEPS];
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
-            const int row = 16 * t + n, j = 4 * s + kk;
+            const int row = 16 * (tile0 + t) + n, j = 4 * s + kk;
             Areg[t][s] = (row < C && j < R) ? pinvT[(size_t)j * C + row] : 0.0;
         }
     const int groups = (B + 4) / 5;
-    for (int g = blockIdx.x * 4 + wave; g < groups; g += gridDim.x * 4) {
+    constexpr int GPB = 4 / SPLIT;               // groups per workgroup and trip
+    for (int g = blockIdx.x * GPB + wave / SPLIT; g < groups; g += gridDim.x * GPB) {
         const int b = 5 * g + bl;
         const bool live = (n < 15) && (b < B);
         double Bv[KSTEPS];
@@ -157,7 +162,7 @@ __global__ void __launch_bounds__(256) k_bspline_fit_mfma(int B, int K, const do
             for (int s = 0; s < KSTEPS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Areg[t][s], Bv[s], acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * t + kk + 4 * r;
+                const int row = 16 * (tile0 + t) + kk + 4 * r;
                 if (live && row < C) out[((size_t)b * C + row) * 3 + ax] = acc[r];
             }
         }
@@ -203,11 +208,11 @@ int launch_bspline_fit(hipStream_t s, int B, int K, const double* pinvT, const d
     if (B <= 0) return hipSuccess;
     const int grid = B < 4096 ? B : 4096;  // 16 waves per CU worth of workgroups, grid-stride beyond
     const int groups = (B + 4) / 5;
-    const int mgrid = groups < 4 * 2048 ? (groups + 3) / 4 : 2048;
-    if (K + 2 <= 32)        // 2 row tiles, K + 4 <= 36 = 9 k-steps
-        hipLaunchKernelGGL((k_bspline_fit_mfma<2, 9>), dim3(mgrid), dim3(256), 0, s, B, K, pinvT, points, conds, out);
-    else if (K + 2 <= 64)   // 4 row tiles, K + 4 <= 68 = 17 k-steps
-        hipLaunchKernelGGL((k_bspline_fit_mfma<4, 17>), dim3(mgrid), dim3(256), 0, s, B, K, pinvT, points, conds, out);
+    auto mgrid = [groups](int gpb) { const int need = (groups + gpb - 1) / gpb; return need < 2048 ? need : 2048; };
+    if (K + 2 <= 32)        // 2 row tiles, K + 4 <= 36 = 9 k-steps, one wave per group
+        hipLaunchKernelGGL((k_bspline_fit_mfma<2, 9, 1>), dim3(mgrid(4)), dim3(256), 0, s, B, K, pinvT, points, conds, out);
+    else if (K + 2 <= 64)   // 4 row tiles, K + 4 <= 68 = 17 k-steps, two waves per group
+        hipLaunchKernelGGL((k_bspline_fit_mfma<2, 17, 2>), dim3(mgrid(2)), dim3(256), 0, s, B, K, pinvT, points, conds, out);
     else
         hipLaunchKernelGGL(k_bspline_fit_gen, dim3(grid), dim3(256), 0, s, B, K, pinvT, points, conds, out);
     return (int)hipGetLastError();
