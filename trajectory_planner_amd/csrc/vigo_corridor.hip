@@ -3,14 +3,15 @@
 // sampler (polyTrajSolver::getPose, PS.cpp:1026-1056), plus the trilinear ESDF query.
 //
 // One 256-thread workgroup per polynomial segment:
-//   pass A  every thread walks chunks of 16 consecutive samples (the chunk's first clock value
-//           comes from accumulated_time(), the rest by the reference's own t += delT), and the
-//           block reduces the samples' bounding box;
+//   bound   the segment's Bernstein coefficients over its sampled time span bound every sample
+//           position (convex hull) — no pass over the samples;
 //   stage   the voxels that box (+ the collision box + 1 voxel) can touch are copied from the
 //           packed HBM planes into an LDS tile as ONE bit per voxel (unknown | occupied — both
 //           mean "collides" for the sweep, PO.cpp:580-588);
-//   pass B  the samples are re-walked and every lattice point of the box sweep is looked up in
-//           the LDS tile (a segment makes ~10^5 lookups inside a few thousand words).
+//   sweep   every thread walks chunks of 16 consecutive samples (the chunk's first clock value
+//           comes from accumulated_time(), the rest by the reference's own t += delT) and looks
+//           every lattice point of the box sweep up in the LDS tile (a segment makes ~10^5
+//           lookups inside a few thousand words).
 // A tile too large for the LDS budget falls back to lookups in the packed planes (L2).
 #include "vigo_exact_time.hpp"
 #include "vigo_grid.hpp"
@@ -175,30 +176,30 @@ __global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A)
 
     const int n_chunks = (n + kChunk - 1) / kChunk;
 
-    // ---- pass A: bounding box of the (float) sample positions ----
-    {
-        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-        for (int c = tid; c < n_chunks; c += kBlock) {
-            const int k0 = c * kChunk, k1 = min(n, k0 + kChunk);
-            double t = accumulated_time(dT, k0);
-            for (int k = k0; k < k1; ++k) {
-                double p[3];
-                poly_pos(cf, deg, t, p);
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const float f = (float)p[a];
-                    lo[a] = fminf(lo[a], f);
-                    hi[a] = fmaxf(hi[a], f);
-                }
-                t += dT;
+    // ---- bound of the sample positions: the Bernstein coefficients of the segment over [0, t_last]
+    //      (convex-hull property: min b_i <= p(t) <= max b_i) — three threads, 8 coefficients each,
+    //      instead of a pass over all samples.  The bound only sizes the LDS tile: a pose whose
+    //      lattice points fall outside the tile takes the L2 path in box_sweep, so results never
+    //      depend on it. ----
+    if (tid < 3 && n > 0) {
+        const double tl = accumulated_time(dT, n - 1);        // clock value of the last sample
+        const double* c = cf + tid * (kMaxDeg + 1);
+        double lo = c[0], hi = c[0];                           // b_0 = c_0
+        // b_i = sum_{k <= i} C(i,k) / C(deg,k) * c_k * tl^k
+        for (int i = 1; i <= deg; ++i) {
+            double bi = c[0], ratio = 1.0, pw = 1.0;
+            for (int k = 1; k <= i; ++k) {
+                ratio *= (double)(i - k + 1) / (double)(deg - k + 1);   // C(i,k)/C(deg,k)
+                pw *= tl;
+                bi += ratio * c[k] * pw;
             }
+            lo = fmin(lo, bi);
+            hi = fmax(hi, bi);
         }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            if (lo[a] <= hi[a]) {  // also false for NaN positions (they collide via the bounds test)
-                atomicMin(&s_min[a], f2ord(lo[a]));
-                atomicMax(&s_max[a], f2ord(hi[a]));
-            }
+        const double pad = 1e-6 * (1.0 + fmax(fabs(lo), fabs(hi)));    // rounding of the conversion and of (float)p
+        if (lo <= hi) {                                        // false for NaN coefficients
+            s_min[tid] = f2ord((float)(lo - pad) - 1e-6f);
+            s_max[tid] = f2ord((float)(hi + pad) + 1e-6f);
         }
     }
     __syncthreads();
