@@ -143,6 +143,26 @@ def test_corridor_checker_matches_oracle(vigo_handle):
         assert f == flag2.cpu().numpy()[s]
 
 
+@pytest.mark.parametrize("deg", [3, 5, 9])
+def test_corridor_checker_other_polynomial_degrees(vigo_handle, deg):
+    """polynomial_degree other than the cfg's 7 (the kernel keeps degree-7 coefficients in registers and
+    walks any other degree from LDS): same bit-exact agreement with the oracle"""
+    v = vigo_handle
+    w = maze_like_world()
+    set_world(v, w)
+    g, keep = ol.make_grid(w)
+    O = ol.oracle()
+    box = np.array([0.4, 0.4, 0.2])
+    coeffs, n_samp, delT, dur = synth.make_corridor_segments(20 + deg, 40, deg=deg, extent_lo=(-4, -4, 0.6), extent_hi=(4, 4, 1.6), n_samples=2000)
+    flag, first, count = (x.cpu().numpy() for x in v.corridor_check(to_dev(coeffs, v.device), to_dev(n_samp, v.device), to_dev(delT, v.device), box, 0.2))
+    for s in range(len(coeffs)):
+        fi, cn = C.c_int(), C.c_int()
+        c = np.ascontiguousarray(coeffs[s])
+        f = O.vgo_corridor_check_segment(C.byref(g), deg, ol._d(c), int(n_samp[s]), float(delT[s]), ol._d(box), 0.2, C.byref(fi), C.byref(cn))
+        assert (f, fi.value, cn.value) == (flag[s], first[s], count[s]), (deg, s)
+    assert 0 < flag.mean() < 1
+
+
 def test_esdf_query_matches_oracle_and_sphere(vigo_handle):
     v = vigo_handle
     n, res = 64, 0.1

@@ -242,22 +242,45 @@ __global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A)
     }
     __syncthreads();
 
-    // ---- pass B: box sweep per sample ----
+    // ---- sweep pass: box sweep per sample ----
     int my_first = 0x7fffffff, my_count = 0;
-    for (int c = tid; c < n_chunks; c += kBlock) {
-        const int k0 = c * kChunk, k1 = min(n, k0 + kChunk);
-        double t = accumulated_time(dT, k0);
-        for (int k = k0; k < k1; ++k) {
-            double p[3];
-            poly_pos(cf, deg, t, p);
-            const float fx = (float)p[0], fy = (float)p[1], fz = (float)p[2];  // pose2Octomap
-            const bool hit = box_sweep(g, A.sweep, fx, fy, fz, &T, tile_words);
-            if (hit) {
-                if (k < my_first) my_first = k;
-                ++my_count;
+    auto walk = [&](auto eval) {
+        for (int c = tid; c < n_chunks; c += kBlock) {
+            const int k0 = c * kChunk, k1 = min(n, k0 + kChunk);
+            double t = accumulated_time(dT, k0);
+            for (int k = k0; k < k1; ++k) {
+                double p[3];
+                eval(t, p);
+                const float fx = (float)p[0], fy = (float)p[1], fz = (float)p[2];  // pose2Octomap
+                const bool hit = box_sweep(g, A.sweep, fx, fy, fz, &T, tile_words);
+                if (hit) {
+                    if (k < my_first) my_first = k;
+                    ++my_count;
+                }
+                t += dT;
             }
-            t += dT;
         }
+    };
+    if (deg == 7) {
+        // the planner's degree (cfg polynomial_degree: 7): coefficients in registers, same operation order
+        double c7[3][8];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int d = 0; d < 8; ++d) c7[a][d] = cf[a * (kMaxDeg + 1) + d];
+        walk([&](double t, double (&p)[3]) {
+            double x = 0, y = 0, z = 0, pw = 1.0;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                x += c7[0][d] * pw;
+                y += c7[1][d] * pw;
+                z += c7[2][d] * pw;
+                pw *= t;
+            }
+            p[0] = x; p[1] = y; p[2] = z;
+        });
+    } else {
+        walk([&](double t, double (&p)[3]) { poly_pos(cf, deg, t, p); });
     }
     if (my_count) {
         atomicMin(&s_first, my_first);
