@@ -83,6 +83,14 @@ for name, f, unit in (("gate: vigo_traj_collision (hasCollisionTrajectory), 1638
     f()
     dt = timeit(f, 30)
     print(json.dumps({"config": name, "ms": dt * 1e3, unit: 16384 / dt}), flush=True)
+bcg = synth.make_bspline_batch(w256, 65536, 32, 77, start_range=8.0)
+dcg = dict(ctrl=T(bcg.ctrl), guide_off=T(bcg.guide_off), guide_pv=T(bcg.guide_pv), guide_unk=T(bcg.guide_unk))
+v.cost_grad(**dcg)
+dt = timeit(lambda: v.cost_grad(**dcg), 30)
+cg_bytes = 65536 * ((6 * 32) * 8 + (3 * 26 + 5) * 8) + bcg.guide_pv.size * 8 + bcg.guide_off.size * 4
+print(json.dumps({"config": "vigo_cost_grad alone: 65536 x 32 ctrl pts (one evaluation)", "ms": dt * 1e3, "evals_per_s": 65536 / dt,
+                  "algorithmic_GBps": cg_bytes / dt / 1e9}), flush=True)
+del bcg, dcg
 tq = T(np.linspace(0.0, 5.8, 233))
 dt = timeit(lambda: v.bspline_eval(ctrl_g, tq), 30)
 print(json.dumps({"config": "bspline::at batched: 16384 x 32 ctrl pts x 233 times", "ms": dt * 1e3, "evals_per_s": 16384 * 233 / dt}), flush=True)
