@@ -333,3 +333,33 @@ def test_parameter_variations_stay_bit_exact(vigo_handle, small_world):
         ce, ge, te = ol.cost_grad_batch(P, b2, w)
     assert np.array_equal(cost.cpu().numpy(), ce) and np.array_equal(grad.cpu().numpy(), ge) and np.array_equal(terms.cpu().numpy(), te)
     assert (terms.cpu().numpy()[:, 3] > 0).any() and len(np.unique(g["status"])) >= 2
+
+
+@pytest.mark.parametrize("scale", [1e-80, 1e-120, float("nan")])
+def test_two_loop_division_fallback_is_exact(vigo_handle, small_world, scale):
+    """The steady-state two-loop divides by ys with Markstein's exact reciprocal sequence, proven for operands
+    within 2^+-500; beyond that (or on a NaN) it repeats the recursion with true divisions.  Control points
+    scaled to 1e-80 / 1e-120 put the dividends (~ scale^2) far below 2^-500 while three of the 40 solves still
+    run all 40 iterations, i.e. through the steady-state path with a full history; a NaN control point covers
+    the other trigger.  Results stay bit-identical to the emulation-mode oracle, which always divides."""
+    v = vigo_handle
+    P = default_params()
+    P.max_iterations = 40
+    P.g_epsilon = 0.0
+    v.set_params(P)
+    b = synth.make_bspline_batch(small_world, 40, 32, 4711, start_range=3.0)
+    rng = np.random.default_rng(3)
+    ctrl = b.ctrl + rng.normal(0, 0.05, size=b.ctrl.shape)
+    if np.isnan(scale):
+        ctrl[7, 10, 1] = np.nan
+        nb = synth.Batch(ctrl, b.guide_off, b.guide_pv, b.guide_unk)
+    else:
+        ctrl = ctrl * scale                                                  # no guides: keeps the problem scale-free
+        nb = synth.Batch(ctrl, np.zeros(b.B * b.N + 1, dtype=np.int32), np.zeros((0, 6)), np.zeros(0, dtype=np.uint8))
+    r = v.optimize(**batch_to_dev(nb, v.device))
+    g = {k: getattr(r, k).cpu().numpy() for k in ("ctrl", "x", "status", "fx", "iters", "evals")}
+    with emulation(32):
+        e = ol.optimize_batch(P, nb)
+    for k in ("status", "iters", "evals", "x", "ctrl", "fx"):
+        assert np.array_equal(g[k], e[k], equal_nan=True), f"{k} differs from the emulation-mode oracle at scale {scale}"
+    assert (g["iters"] > 20).any()                                            # the history did fill up: the steady path ran

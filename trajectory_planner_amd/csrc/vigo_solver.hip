@@ -188,6 +188,39 @@ __device__ __forceinline__ double dot_lane(const T (&a)[PPL][3], const T (&b)[PP
     return s;
 }
 
+// ys of a history pair as the two-loop uses it (LB:1300, :1312 divide by it).  FAST keeps only the
+// reciprocal in v.  The reference-order mode keeps ys in v and its correctly rounded reciprocal in
+// r: the steady-state two-loop divides with Markstein's sequence q = a*r, e = fma(-q, ys, a),
+// q' = fma(e, r, q) — the correctly rounded a/ys, the same bits as the 13-instruction fp64
+// division, whenever r = RN(1/ys) and nothing over/underflows (Markstein 1990; checked against
+// 4e8 random divisions incl. all-ones significands).  r is NaN for a ys outside 2^+-500, the
+// dividends' magnitudes are tracked with one max and one min per step, and a two-loop that saw a
+// dividend outside 2^+-500 (or produced a NaN) is repeated with true divisions.
+struct YS {
+    double v, r;
+};
+__device__ __forceinline__ bool exp_in_safe_range(double a) {
+    const unsigned e = ((unsigned)__double2hiint(a) >> 20) & 0x7ffu;
+    return (e - 523u) < 1000u;
+}
+template <bool FAST>
+__device__ __forceinline__ YS make_ys(double ys) {
+    YS o;
+    o.v = FAST ? 1.0 / ys : ys;
+    o.r = FAST ? 0.0 : (exp_in_safe_range(ys) ? 1.0 / ys : __builtin_nan(""));
+    return o;
+}
+template <bool FAST, bool MARK>
+__device__ __forceinline__ double over_ys(double a, const YS& y, double& amin, double& amax) {
+    if (FAST) return a * y.v;
+    if (!MARK) return a / y.v;
+    const double q = a * y.r;
+    const double e = __builtin_fma(-q, y.v, a);
+    amin = fmin(amin, fabs(a));
+    amax = fmax(amax, fabs(a));
+    return __builtin_fma(e, y.r, q);
+}
+
 // one L-BFGS history pair of one control point as it sits in LDS (48 B in fp64: three
 // conflict-free ds_read_b128 per lane, one address register)
 template <typename T>
@@ -704,6 +737,9 @@ __device__ __forceinline__ int trial_interval(double& xt, double& xf, double& xd
 #ifndef VIGO_TWOLOOP_STEADY
 #define VIGO_TWOLOOP_STEADY 1
 #endif
+#ifndef VIGO_TWOLOOP_MARKSTEIN
+#define VIGO_TWOLOOP_MARKSTEIN 1
+#endif
 template <typename T, int GROUP, int PPL, bool FAST>
 __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevConst* __restrict__ Kp) {
     const DevConst& K = *Kp;  // uniform address: scalar loads at the use sites, not 100+ live SGPRs
@@ -736,11 +772,11 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
         const int pc = (p < 3) ? 3 : ((p > N - 4) ? N - 4 : p);
         hl[q] = hist + (grp * NI + (pc - 3));
     }
-    double* ys_l = ys_tab + grp;
-    double* al_l = ys_tab + (size_t)m * TPB + grp;
+    YS* ys_l = reinterpret_cast<YS*>(ys_tab) + grp;
+    double* al_l = ys_tab + 2 * (size_t)m * TPB + grp;
     if (A.obs) {
         // stage this trajectory's obstacles (BT.cpp:1011-1015 operands) once; size in T arithmetic
-        double* oc = ys_tab + 2 * (size_t)m * TPB + (size_t)grp * kObsCache * kObsRec;
+        double* oc = ys_tab + 3 * (size_t)m * TPB + (size_t)grp * kObsCache * kObsRec;
         const int cnt = Q.o_end - Q.o_begin;
         Q.o_cached = cnt < kObsCache ? cnt : kObsCache;
         Q.obs_cache = oc;
@@ -765,7 +801,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
 #pragma unroll
         for (int a = 0; a < 3; ++a) g[q][a] = xp[q][a] = gp[q][a] = d[q][a] = T(0);
     T s1[PPL][3], y1[PPL][3];   // REG1: the age-1 pair of the next two-loop
-    double ys1 = 0.0;
+    YS ys1 = {0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < PPL; ++q)
 #pragma unroll
@@ -913,7 +949,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
         group_sum<GROUP, 2>(ysyy);
         const double ys = ysyy[0], yy = ysyy[1];
         // the two-loop divides by ys of each pair (LB:1300, :1312); FAST keeps its reciprocal instead
-        const double ys_div = FAST ? 1.0 / ys : ys;
+        const YS ys_div = make_ys<FAST>(ys);
         if (!REG1) ys_l[end * TPB] = ys_div;
         const bool have1 = REG1 && k >= 2;   // s1/y1 hold the previous iteration's pair (age 1 now)
 
@@ -933,8 +969,8 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
 
         constexpr int kWin = VIGO_TWOLOOP_WIN;
         T Ps[kWin][PPL][3], Py[kWin][PPL][3];
-        double Pys[kWin];
-        auto fetch = [&](int age, T (&s_)[PPL][3], T (&y_)[PPL][3], double& ys_) {
+        YS Pys[kWin];
+        auto fetch = [&](int age, T (&s_)[PPL][3], T (&y_)[PPL][3], YS& ys_) {
             // (age is a literal after unrolling: the register cases fold away)
             if (REG1 && age == 0) {
 #pragma unroll
@@ -966,23 +1002,25 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
         // bound` is true at compile time, so the 32 steps are straight-line code — no exec-mask
         // blocks, no merge copies of the window registers, LDS fetches hoisted freely — and the
         // alphas stay in registers.  Same operations in the same order as the general path.
-        auto two_loop = [&](auto steady_tag) {
+        auto two_loop = [&](auto steady_tag) -> bool {
             constexpr bool STEADY = decltype(steady_tag)::value;
+            constexpr bool MARK = STEADY && !FAST && VIGO_TWOLOOP_MARKSTEIN;
+            double amin = 1.0, amax = 1.0;
             const int bnd = STEADY ? kMaxMem : bound;
             double al_reg[STEADY ? kMaxMem : 1];
             // STEADY: the LDS ring (kMaxMem - 2 slots) is walked with running byte offsets — one
             // add and a wrap per fetch instead of slot arithmetic and two quarter-rate multiplies
             constexpr int kRing = kMaxMem - 2;
-            const int stepB = ROW * (int)sizeof(HPair<T>), stepY = TPB * (int)sizeof(double);
+            const int stepB = ROW * (int)sizeof(HPair<T>), stepY = TPB * (int)sizeof(YS);
             int curB = last * stepB, curY = last * stepY;   // slot of the age-2 pair
-            auto ring_fetch = [&](T (&s_)[PPL][3], T (&y_)[PPL][3], double& ys_) {
+            auto ring_fetch = [&](T (&s_)[PPL][3], T (&y_)[PPL][3], YS& ys_) {
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) {
                     const HPair<T> h = *reinterpret_cast<const HPair<T>*>(reinterpret_cast<const char*>(hl[q]) + curB);
 #pragma unroll
                     for (int a = 0; a < 3; ++a) { s_[q][a] = h.s[a]; y_[q][a] = h.y[a]; }
                 }
-                ys_ = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ys_l) + curY);
+                ys_ = *reinterpret_cast<const YS*>(reinterpret_cast<const char*>(ys_l) + curY);
             };
             auto ring_older = [&]() {   // towards higher ages: one slot down, wrapping
                 curB -= stepB; curY -= stepY;
@@ -1005,7 +1043,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
                 if (age < bnd) {
                     const int w = age % kWin;
                     double al = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(Ps[w], d));
-                    if (FAST) al *= Pys[w]; else al /= Pys[w];
+                    al = over_ys<FAST, MARK>(al, Pys[w], amin, amax);
                     if (STEADY) al_reg[STEADY ? age : 0] = al;
                     else al_l[age * TPB] = al;         // alpha_j parks in LDS at a static offset
 #pragma unroll
@@ -1042,7 +1080,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
                 if (age < bnd) {
                     const int w = age % kWin;
                     double beta = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(Py[w], d));
-                    if (FAST) beta *= Pys[w]; else beta /= Pys[w];
+                    beta = over_ys<FAST, MARK>(beta, Pys[w], amin, amax);
                     const double cod = (STEADY ? al_reg[STEADY ? age : 0] : al_l[age * TPB]) - beta;
 #pragma unroll
                     for (int q = 0; q < PPL; ++q) {
@@ -1056,9 +1094,28 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
                     }
                 }
             }
+            if (!MARK) return false;
+            bool bad = !(amin >= 0x1p-500) || !(amax <= 0x1p500);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) bad |= !(d[q][a] == d[q][a]);
+            return bad;
         };
-        if (VIGO_TWOLOOP_STEADY && PPL == 1 && bound == kMaxMem) two_loop(std::true_type{});
-        else two_loop(std::false_type{});
+        if (VIGO_TWOLOOP_STEADY && PPL == 1 && bound == kMaxMem) {
+            if (__any(two_loop(std::true_type{}))) {
+                // a dividend outside the range Markstein's sequence is proven for (or a NaN): the same
+                // recursion again from d = -g on the general path, which divides for real
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) d[q][a] = -g[q][a];
+                two_loop(std::false_type{});
+            }
+        } else {
+            two_loop(std::false_type{});
+        }
         if (REG1) {
             // the age-1 pair turns age 2 for the next two-loop: it leaves the registers for the LDS
             // ring (overwriting the pair that would be age m), the new pair takes its place
@@ -1109,7 +1166,7 @@ size_t optimize_lds_bytes(int N, int m, int ppl, bool with_obstacles) {
     const int ms = ppl == 1 ? (m > 2 ? m - 2 : 0) : m;   // REG1: ages 0 and 1 live in registers
     size_t h = (size_t)ms * TPB * (N - 6) * sizeof(HPair<T>);
     h = (h + 15) & ~(size_t)15;
-    h += 2 * (size_t)m * TPB * sizeof(double);
+    h += 3 * (size_t)m * TPB * sizeof(double);   // {ys, 1/ys} per slot + the alphas
     if (with_obstacles) h += (size_t)TPB * kObsCache * kObsRec * sizeof(double);
     return h;
 }
