@@ -190,29 +190,32 @@ __device__ __forceinline__ double dot_lane(const T (&a)[PPL][3], const T (&b)[PP
 
 // ys of a history pair as the two-loop uses it (LB:1300, :1312 divide by it).  FAST keeps only the
 // reciprocal in v.  The reference-order mode keeps ys in v and its correctly rounded reciprocal in
-// r: the steady-state two-loop divides with Markstein's sequence q = a*r, e = fma(-q, ys, a),
+// r (YSv<false>): the steady-state two-loop divides with Markstein's sequence q = a*r, e = fma(-q, ys, a),
 // q' = fma(e, r, q) — the correctly rounded a/ys, the same bits as the 13-instruction fp64
 // division, whenever r = RN(1/ys) and nothing over/underflows (Markstein 1990; checked against
 // 4e8 random divisions incl. all-ones significands).  r is NaN for a ys outside 2^+-500, the
 // dividends' magnitudes are tracked with one max and one min per step, and a two-loop that saw a
 // dividend outside 2^+-500 (or produced a NaN) is repeated with true divisions.
-struct YS {
+template <bool FAST>
+struct YSv {            // reference-order mode
     double v, r;
+};
+template <>
+struct YSv<true> {      // FAST: the reciprocal only
+    double v;
 };
 __device__ __forceinline__ bool exp_in_safe_range(double a) {
     const unsigned e = ((unsigned)__double2hiint(a) >> 20) & 0x7ffu;
     return (e - 523u) < 1000u;
 }
-template <bool FAST>
-__device__ __forceinline__ YS make_ys(double ys) {
-    YS o;
-    o.v = FAST ? 1.0 / ys : ys;
-    o.r = FAST ? 0.0 : (exp_in_safe_range(ys) ? 1.0 / ys : __builtin_nan(""));
-    return o;
+__device__ __forceinline__ YSv<true> make_ys(double ys, YSv<true>*) { return YSv<true>{1.0 / ys}; }
+__device__ __forceinline__ YSv<false> make_ys(double ys, YSv<false>*) {
+    return YSv<false>{ys, exp_in_safe_range(ys) ? 1.0 / ys : __builtin_nan("")};
 }
-template <bool FAST, bool MARK>
-__device__ __forceinline__ double over_ys(double a, const YS& y, double& amin, double& amax) {
-    if (FAST) return a * y.v;
+template <bool MARK>
+__device__ __forceinline__ double over_ys(double a, const YSv<true>& y, double&, double&) { return a * y.v; }
+template <bool MARK>
+__device__ __forceinline__ double over_ys(double a, const YSv<false>& y, double& amin, double& amax) {
     if (!MARK) return a / y.v;
     const double q = a * y.r;
     const double e = __builtin_fma(-q, y.v, a);
@@ -772,6 +775,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
         const int pc = (p < 3) ? 3 : ((p > N - 4) ? N - 4 : p);
         hl[q] = hist + (grp * NI + (pc - 3));
     }
+    using YS = YSv<FAST>;
     YS* ys_l = reinterpret_cast<YS*>(ys_tab) + grp;
     double* al_l = ys_tab + 2 * (size_t)m * TPB + grp;
     if (A.obs) {
@@ -801,7 +805,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
 #pragma unroll
         for (int a = 0; a < 3; ++a) g[q][a] = xp[q][a] = gp[q][a] = d[q][a] = T(0);
     T s1[PPL][3], y1[PPL][3];   // REG1: the age-1 pair of the next two-loop
-    YS ys1 = {0.0, 0.0};
+    YS ys1{};
 #pragma unroll
     for (int q = 0; q < PPL; ++q)
 #pragma unroll
@@ -949,7 +953,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
         group_sum<GROUP, 2>(ysyy);
         const double ys = ysyy[0], yy = ysyy[1];
         // the two-loop divides by ys of each pair (LB:1300, :1312); FAST keeps its reciprocal instead
-        const YS ys_div = make_ys<FAST>(ys);
+        const YS ys_div = make_ys(ys, static_cast<YS*>(nullptr));
         if (!REG1) ys_l[end * TPB] = ys_div;
         const bool have1 = REG1 && k >= 2;   // s1/y1 hold the previous iteration's pair (age 1 now)
 
@@ -1043,7 +1047,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
                 if (age < bnd) {
                     const int w = age % kWin;
                     double al = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(Ps[w], d));
-                    al = over_ys<FAST, MARK>(al, Pys[w], amin, amax);
+                    al = over_ys<MARK>(al, Pys[w], amin, amax);
                     if (STEADY) al_reg[STEADY ? age : 0] = al;
                     else al_l[age * TPB] = al;         // alpha_j parks in LDS at a static offset
 #pragma unroll
@@ -1080,7 +1084,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
                 if (age < bnd) {
                     const int w = age % kWin;
                     double beta = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(Py[w], d));
-                    beta = over_ys<FAST, MARK>(beta, Pys[w], amin, amax);
+                    beta = over_ys<MARK>(beta, Pys[w], amin, amax);
                     const double cod = (STEADY ? al_reg[STEADY ? age : 0] : al_l[age * TPB]) - beta;
 #pragma unroll
                     for (int q = 0; q < PPL; ++q) {
