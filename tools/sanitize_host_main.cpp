@@ -1,0 +1,42 @@
+#include <trajectory_planner/octomapBt.h>
+#include <trajectory_planner/polyTrajSolver.h>
+#include <trajectory_planner/bspline.h>
+#include <trajectory_planner/path_search/astarOcc.h>
+#include <cstdio>
+#include <random>
+int main(int argc, char** argv) {
+    using namespace trajPlanner;
+    int fails = 0;
+    const double inflate[3] = {0.1, 0.1, 0.0};
+    for (int i = 1; i < argc; ++i) {
+        BtInfo bi;
+        auto m = loadOctomapBt(argv[i], inflate, 2, &bi);
+        std::printf("%s: %s nodes %lld/%lld dims %d %d %d\n", argv[i], m ? "ok" : "FAILED", bi.nodes_parsed, bi.nodes_header, m ? m->nx() : 0, m ? m->ny() : 0, m ? m->nz() : 0);
+        if (!m || bi.nodes_parsed != bi.nodes_header) ++fails;
+    }
+    std::mt19937_64 rng(7);
+    std::uniform_real_distribution<double> U(-1, 1);
+    for (int trial = 0; trial < 300; ++trial) {
+        const int W = 2 + trial % 10;
+        std::vector<pose> path;
+        double x = 0, y = 0;
+        for (int i = 0; i < W; ++i) { path.push_back(pose(x, y, 1.0 + 0.1 * U(rng))); x += 1.0 + 2.0 * std::fabs(U(rng)); y += 2.0 * U(rng); }
+        polyTrajSolver s(7, 4, 4, 1.0);
+        s.updatePath(path);
+        if (trial % 3) s.setCorridorConstraint(std::vector<double>(W - 1, 0.05 + 0.5 * std::fabs(U(rng))), 8.0);
+        const bool ok = s.solve();
+        if (ok) { std::vector<pose> tr; s.getTrajectory(tr, 0.1); if (tr.empty()) ++fails; }
+    }
+    // B-spline fit + evaluation
+    for (int K = 4; K < 70; K += 7) {
+        std::vector<Eigen::Vector3d> pts, cond(4, Eigen::Vector3d(0.1, -0.2, 0.0));
+        for (int i = 0; i < K; ++i) pts.push_back(Eigen::Vector3d(0.25 * i, 0.1 * U(rng), 1.0));
+        Eigen::MatrixXd C;
+        if (!bspline::parameterizeToBspline(0.2, pts, cond, C) || C.cols() != K + 2) ++fails;
+        bspline b(3, C, 0.2);
+        for (double t = 0; t <= b.getDuration(); t += 0.05) (void)b.at(t);
+        (void)b.getDerivative().getDerivative().at(0.3);
+    }
+    std::printf("%s\n", fails ? "FAILED" : "sanitizer run complete, no failures");
+    return fails;
+}
