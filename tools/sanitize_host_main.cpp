@@ -37,6 +37,19 @@ int main(int argc, char** argv) {
         for (double t = 0; t <= b.getDuration(); t += 0.05) (void)b.at(t);
         (void)b.getDerivative().getDerivative().at(0.3);
     }
+    // A* on a small map with a wall and a gap (guide search of the B-spline planner)
+    {
+        auto m = std::make_shared<mapManager::occMap>(64, 64, 20, Eigen::Vector3d(-3.2, -3.2, 0.0), 0.1);
+        for (int iy = 0; iy < 64; ++iy)
+            for (int iz = 0; iz < 20; ++iz)
+                if (iy < 20 || iy > 26) m->at(32, iy, iz) |= 5;
+        AStar a;
+        a.initGridMap(m, Eigen::Vector3i(100, 100, 100), 0.0, 2.0);
+        for (int k = 0; k < 20; ++k) {
+            const bool found = a.AstarSearch(0.1, Eigen::Vector3d(-2.0, 2.0 * U(rng), 1.0), Eigen::Vector3d(2.0, 2.0 * U(rng), 1.0));
+            if (found && a.getPath().size() < 2) ++fails;
+        }
+    }
     std::printf("%s\n", fails ? "FAILED" : "sanitizer run complete, no failures");
     return fails;
 }
