@@ -93,7 +93,7 @@ typedef struct {
     int32_t plan_in_z;           /* planInZAxis_           BT.cpp:98   */
     /* L-BFGS (lbfgs_parameter_t, LB:87-191) */
     int32_t mem_size;            /* BT.cpp:697 (16)  */
-    int32_t max_iterations;      /* BT.cpp:698 (200) */
+    int32_t max_iterations;      /* BT.cpp:698 (200); 0 (= unbounded in lbfgs.hpp) is refused */
     int32_t max_linesearch;      /* LB:948 (40)      */
     int32_t past;                /* LB:945 (0); only 0 is supported */
     int32_t reserved_;

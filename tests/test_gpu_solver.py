@@ -133,6 +133,11 @@ def test_edge_cases(vigo_handle, small_world):
         v.optimize(torch.zeros(1, 257, 3, dtype=torch.float64, device=dev))     # > VIGO_MAX_CTRL_POINTS
     with pytest.raises(VigoError):
         v.optimize(torch.zeros(1, 230, 3, dtype=torch.float64, device=dev))     # history does not fit 160 KiB of LDS
+    # the unbounded setting of lbfgs.hpp (max_iterations = 0) is refused: every wave must reach an exit
+    P0 = default_params()
+    P0.max_iterations = 0
+    with pytest.raises(VigoError):
+        v.set_params(P0)
     # max_iterations = 1 and mem_size = 3 (history ring wraps many times)
     for (iters, mem) in ((1, 16), (50, 3), (50, 1)):
         P2 = default_params()

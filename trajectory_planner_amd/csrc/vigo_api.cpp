@@ -184,7 +184,14 @@ int vigo_set_params(vigo_handle_t h, const vigo_params_t* p) {
     if (!h || !p) return VIGO_ERR_INVALID_ARG;
     if (p->mem_size <= 0 || p->mem_size > VIGO_MAX_MEM_SIZE) return fail(h, VIGO_ERR_UNSUPPORTED, "mem_size outside [1, VIGO_MAX_MEM_SIZE]");
     if (p->past != 0) return fail(h, VIGO_ERR_UNSUPPORTED, "past != 0 (delta test) is not implemented; the reference runs past = 0");
+    // lbfgs.hpp treats max_iterations == 0 as "until convergence or error" (LB:127-131); a device kernel
+    // must have a bound every wave reaches, so the unbounded setting is refused (the reference runs 200)
+    if (p->max_iterations == 0) return fail(h, VIGO_ERR_UNSUPPORTED, "max_iterations == 0 (unbounded) is not supported on the device");
     if (!(p->ts > 0) || !(p->ts_ctrl > 0)) return fail(h, VIGO_ERR_INVALID_ARG, "ts and ts_ctrl must be > 0");
+    // predictionNum = int(predHorizon / ts) divides n in the dynamic-obstacle term (BT.cpp:1006, :1020): 0 is a
+    // division by zero in the reference; a huge value is an unbounded device loop
+    if (!(p->pred_horizon / p->ts >= 1.0) || !(p->pred_horizon / p->ts <= 100000.0))
+        return fail(h, VIGO_ERR_INVALID_ARG, "pred_horizon / ts must lie in [1, 1e5]");
     // the argument checks of lbfgs_optimize (LB:1060-1104): refuse here rather than per trajectory
     if (p->g_epsilon < 0. || p->delta < 0. || p->min_step < 0. || p->max_step < p->min_step ||
         p->f_dec_coeff < 0. || p->s_curv_coeff <= p->f_dec_coeff || 1. <= p->s_curv_coeff ||
