@@ -232,6 +232,8 @@ def main():
         elapsed = max_over_ranks(elapsed)
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    iters = res.iters.cpu().numpy()      # of the timed configuration (the side measurements below overwrite res)
+    evals = res.evals.cpu().numpy()
 
     # ---- side measurements (outside the timed region above; rank 0 of a single-GPU run only) ----
     extra = {}
@@ -276,8 +278,23 @@ def main():
         dt = (time.perf_counter() - t1) / k2
         extra["other_mode"] = {"arithmetic": other, "value": B / dt, "unit": "trajectories/s", "ms_per_step": dt * 1e3}
         v.set_precision({"f32": PREC_F32, "f64": PREC_F64, "f64_fast": 2}[args.precision])
-    iters = res.iters.cpu().numpy()
-    evals = res.evals.cpu().numpy()
+        # (c) fixed work: g_epsilon = 0 switches the convergence exit off, every trajectory runs all iterations
+        #     (SURVEY.md §8(d) asks for both; `value` above is the reference-faithful g_epsilon = 0.01)
+        geps = float(P.g_epsilon)
+        P.g_epsilon = 0.0
+        v.set_params(P)
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / k2
+        extra["fixed_work_g_epsilon_0"] = {"value": B / dt, "unit": "trajectories/s", "ms_per_step": dt * 1e3,
+                                            "mean_iters": float(res.iters.float().mean().item())}
+        P.g_epsilon = geps
+        v.set_params(P)
     gp = np.diff(batch.guide_off).reshape(B, N).sum(1)
     elem = 4 if args.precision == "f32" else 8
     alg_bytes = float(algorithmic_bytes(n, P.mem_size, iters, evals, gp, elem).sum())
