@@ -77,3 +77,19 @@ def test_accumulated_time_equals_the_reference_loop():
             k_done = k
             assert lib.vigo_accumulated_time(d, k) == t, (d, k)
     assert lib.vigo_accumulated_time(0.0, 5) == 0.0
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/vigo.h must compile as C99 and as C++14 (the reference's standard, CMakeLists.txt:6) on its own:
+    no C++ or torch types at the boundary"""
+    import subprocess
+    src = tmp_path / "use_vigo.c"
+    src.write_text('#include "vigo.h"\nint main(void) { vigo_params_t p; vigo_default_params(&p); return (int)sizeof(vigo_handle_t) == 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)], check=True)
+    subprocess.run(["g++", "-std=c++14", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)], check=True)
+    # and it links: every declared entry point resolves against the built library (no GPU needed to link)
+    lib_dir = os.path.join(ROOT, "trajectory_planner_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(tmp_path / "use_vigo"), "-L", lib_dir, "-lvigo_hip",
+                    "-Wl,-rpath," + lib_dir], check=True)
+    assert subprocess.run([str(tmp_path / "use_vigo")]).returncode == 0
