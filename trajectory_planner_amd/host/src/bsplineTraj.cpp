@@ -9,6 +9,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <atomic>
+#include <thread>
+#include <cstdlib>
 #include <cmath>
 #include <fstream>
 #include <cstring>
@@ -26,7 +29,8 @@ namespace {
 struct DevBuf {
     void* p = nullptr;
     size_t n = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool keep = false;   // thread-lifetime staging buffers: left to the runtime's teardown, not freed after it
+    ~DevBuf() { if (p && !keep) (void)hipFree(p); }
     bool upload(const void* src, size_t bytes) {
         if (bytes > n) {
             if (p) (void)hipFree(p);
@@ -47,6 +51,25 @@ struct DevBuf {
         return true;
     }
     bool download(void* dst, size_t bytes) const { return hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost) == hipSuccess; }
+};
+
+// fn(i) for i in [0, n) on up to 16 host threads (planner-local work only)
+template <typename F>
+void parallelFor(size_t n, F fn) {
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned nthr = (unsigned)std::min<size_t>(hw, std::max<size_t>(1, n / 8));
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+}
+
+struct StagingBuf : DevBuf {
+    StagingBuf() { keep = true; }
 };
 
 double wallSeconds() {
@@ -283,7 +306,7 @@ std::vector<bool> bsplineTraj::updatePathBatch(const std::vector<bsplineTraj*>& 
             for (int i = 0; i < 4; ++i)
                 for (int q = 0; q < 3; ++q) cond[((size_t)b * 4 + i) * 3 + q] = startEndConditions[grp[b]][i](q);
         }
-        DevBuf dPts, dCond, dCtrl;
+        static thread_local StagingBuf dPts, dCond, dCtrl;
         if (!dPts.upload(pts.data(), pts.size() * 8) || !dCond.upload(cond.data(), cond.size() * 8) || !dCtrl.alloc(ctrl.size() * 8)) continue;
         if (vigo_bspline_fit(lead->dev_, B, K, ts, (const double*)dPts.p, (const double*)dCond.p, (double*)dCtrl.p) != VIGO_OK) {
             cout << "[BsplineTraj]: vigo_bspline_fit failed: " << vigo_last_error(lead->dev_) << endl;
@@ -615,7 +638,9 @@ void bsplineTraj::solveBatch(const std::vector<bsplineTraj*>& ps) {
             hb.weights.push_back(p->weightDynamicObstacle_);
         }
         const size_t G = hb.gpv.size() / 6;
-        DevBuf dCtrl, dGoff, dGpv, dGunk, dOoff, dObs, dW, dStatus;
+        // device staging buffers live across calls (one set per host thread): hipMalloc/hipFree per
+        // rebound round cost more than the round's kernels
+        static thread_local StagingBuf dCtrl, dGoff, dGpv, dGunk, dOoff, dObs, dW, dStatus;
         bool ok = dCtrl.upload(hb.ctrl.data(), hb.ctrl.size() * 8) && dGoff.upload(hb.goff.data(), hb.goff.size() * 4) &&
                   dGpv.upload(hb.gpv.data(), hb.gpv.size() * 8) && dGunk.alloc(G) && dOoff.upload(hb.ooff.data(), hb.ooff.size() * 4) &&
                   dObs.upload(hb.obs.data(), hb.obs.size() * 8) && dW.upload(hb.weights.data(), hb.weights.size() * 8) &&
@@ -671,7 +696,7 @@ void bsplineTraj::gateBatch(const std::vector<bsplineTraj*>& ps, std::vector<uin
             ooff.push_back((int32_t)(obs.size() / 9));
         }
         const int B = (int)idx.size();
-        DevBuf dCtrl, dFlag, dDyn, dOoff, dObs;
+        static thread_local StagingBuf dCtrl, dFlag, dDyn, dOoff, dObs;
         if (!dCtrl.upload(ctrl.data(), ctrl.size() * 8) || !dFlag.alloc(B) || !dDyn.alloc(B) ||
             !dOoff.upload(ooff.data(), ooff.size() * 4) || !dObs.upload(obs.data(), obs.size() * 8))
             continue;
@@ -899,19 +924,30 @@ std::vector<bool> bsplineTraj::makePlanBatch(const std::vector<bsplineTraj*>& pl
     std::vector<Rebound> rb(P);
     std::vector<bsplineTraj*> active;
     std::vector<size_t> activeIdx;
+    // steps 1-3 (collision segments, A*, guide assignment) touch only the planner's own state and the
+    // read-only map: the planners are spread over the host cores
+    const double tp0 = wallSeconds();
+    std::vector<uint8_t> prepared(P, 0);
+    parallelFor(P, [&](size_t i) {
+        bsplineTraj* p = planners[i];
+        if (!p->init_ || !p->map_) return;
+        p->findCollisionSeg(p->optData_.controlPoints, p->collisionSeg_);           // step 1
+        if (!p->pathSearch(p->collisionSeg_, p->astarPaths_)) return;               // step 2
+        p->assignGuidePointsSemiCircle(p->astarPaths_, p->collisionSeg_);           // step 3
+        prepared[i] = 1;
+    });
     for (size_t i = 0; i < P; ++i) {
         bsplineTraj* p = planners[i];
         if (!p->init_ || !p->map_) continue;
-        p->findCollisionSeg(p->optData_.controlPoints, p->collisionSeg_);           // step 1
-        if (!p->pathSearch(p->collisionSeg_, p->astarPaths_)) {                     // step 2
+        if (!prepared[i]) {
             cout << "[BsplineTraj]: Fail because of A* failure." << endl;
             continue;
         }
-        p->assignGuidePointsSemiCircle(p->astarPaths_, p->collisionSeg_);           // step 3
         p->reboundBegin(rb[i]);
         active.push_back(p);
         activeIdx.push_back(i);
     }
+    const double tp1 = wallSeconds();
     // step 4: rebound loops.  The 30 ms budget of BT.cpp:633 is per makePlan() call in the
     // reference; a batch keeps it per round so one slow planner cannot starve the others.
     solveBatch(active);
@@ -923,9 +959,11 @@ std::vector<bool> bsplineTraj::makePlanBatch(const std::vector<bsplineTraj*>& pl
         const bool timedOut = wallSeconds() - t0 > budget;
         std::vector<bsplineTraj*> next, solve;
         std::vector<size_t> nextIdx;
+        // one pass of the loop body per planner (validation outcome -> re-guide / weight doubling, BT.cpp:619-681):
+        // planner-local, incl. the A* of a re-guide, so spread over the host cores
+        parallelFor(active.size(), [&](size_t a) { active[a]->reboundStep(rb[activeIdx[a]], col[a] != 0, dyn[a] != 0, timedOut); });
         for (size_t a = 0; a < active.size(); ++a) {
             Rebound& r = rb[activeIdx[a]];
-            active[a]->reboundStep(r, col[a] != 0, dyn[a] != 0, timedOut);
             if (r.done) {
                 result[activeIdx[a]] = r.ok;
                 if (!r.ok) cout << "[BsplineTraj]: Fail because of optimizer not finding a solution." << endl;
@@ -939,12 +977,17 @@ std::vector<bool> bsplineTraj::makePlanBatch(const std::vector<bsplineTraj*>& pl
         active.swap(next);
         activeIdx.swap(nextIdx);
     }
-    for (size_t i = 0; i < P; ++i) {
-        if (!result[i]) continue;
+    const double tp2 = wallSeconds();
+    std::vector<uint8_t> okv(result.begin(), result.end());
+    parallelFor(P, [&](size_t i) {
+        if (!okv[i]) return;
         bsplineTraj* p = planners[i];
         p->bspline_ = trajPlanner::bspline(bsplineDegree, p->optData_.controlPoints, p->controlPointsTs_);  // step 5
         p->linearFeasibilityReparam();                                                                  // step 6
-    }
+    });
+    if (getenv("VIGO_FACADE_TIMING"))
+        cout << "[BsplineTraj]: makePlanBatch of " << P << ": prologue " << (tp1 - tp0) * 1e3 << " ms, rebound loop " << (tp2 - tp1) * 1e3
+             << " ms, epilogue " << (wallSeconds() - tp2) * 1e3 << " ms" << endl;
     return result;
 }
 

@@ -4,6 +4,7 @@
 #include <trajectory_planner/bsplineTraj.h>
 #include <trajectory_planner/polyTrajOctomap.h>
 
+#include <chrono>
 #include <cmath>
 #include <iostream>
 #include <cstdio>
@@ -169,6 +170,35 @@ int main() {
         }
         std::printf("INFO batch: %d of %zu planned, %d verified collision free\n", good, ps.size(), clean);
         CHECK(good >= 40 && clean == good, "makePlanBatch plans the batch and every success is collision free");
+    }
+
+    // ---- application-level rate: 1024 planners through updatePathBatch + makePlanBatch (host A*, guide
+    //      assignment and bookkeeping included), reported, not gated ----
+    {
+        const int NP = 1024;
+        std::vector<std::unique_ptr<bsplineTraj>> owners;
+        std::vector<bsplineTraj*> ps;
+        std::vector<nav_msgs::Path> paths;
+        for (int i = 0; i < NP; ++i) {
+            owners.emplace_back(new bsplineTraj(makeParams()));
+            owners.back()->setMap(map);
+            owners.back()->updateMaxVel(2.0);
+            owners.back()->updateMaxAcc(3.0);
+            ps.push_back(owners.back().get());
+            const double y = -2.6 + 5.2 * (i % 97) / 96.0, tilt = 0.4 * ((i * 37) % 11 - 5) / 5.0;
+            paths.push_back(straight(-3.0, y, 3.0, y + tilt, 1.0, 0.25));
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<bool> up = bsplineTraj::updatePathBatch(ps, paths, std::vector<std::vector<Eigen::Vector3d>>(NP, cond));
+        const auto t1 = std::chrono::steady_clock::now();
+        std::vector<bool> res = bsplineTraj::makePlanBatch(ps);
+        const auto t2 = std::chrono::steady_clock::now();
+        int good = 0, clean = 0;
+        for (int i = 0; i < NP; ++i) { good += res[i]; if (res[i] && ps[i]->isCurrTrajValid()) ++clean; }
+        const double msU = std::chrono::duration<double, std::milli>(t1 - t0).count(), msP = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        std::printf("INFO 1024 planners: updatePathBatch %.2f ms, makePlanBatch %.2f ms (%.0f plans/s end to end), %d planned, %d verified collision free\n",
+                    msU, msP, NP / ((msU + msP) * 1e-3), good, clean);
+        CHECK(good >= NP * 8 / 10 && clean == good, "1024-planner batch: every success is collision free");
     }
 
     // ---- polyTrajOctomap checker ----
