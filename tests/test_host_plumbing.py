@@ -22,6 +22,8 @@ def host():
     L = C.CDLL(LIB)
     L.vigo_host_bt_info.argtypes = [C.c_char_p, C.POINTER(C.c_longlong), _dp, _dp]
     L.vigo_host_bt_load.argtypes = [C.c_char_p, _dp, C.c_int, C.c_void_p, C.c_longlong, C.POINTER(C.c_int), _dp]
+    L.vigo_host_pcd_load.argtypes = [C.c_char_p, C.c_double, _dp, C.c_int, C.c_void_p, C.c_longlong, C.POINTER(C.c_int), _dp,
+                                     C.POINTER(C.c_longlong)]
     L.vigo_host_minsnap.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_double, _dp, _dp]
     return L
 
@@ -139,6 +141,46 @@ def test_bt_reader_on_the_reference_maps(host):
         if path.endswith("maze.bt"):
             assert info[0] == 341148 and res.value == pytest.approx(0.1)
             assert (info[5], info[6], info[7]) == (219, 205, 41)
+
+
+def pcd_load(host, path, res, inflate=(0.0, 0.0, 0.0), margin=1):
+    dims, origin, npts = (C.c_int * 3)(), (C.c_double * 3)(), C.c_longlong()
+    infl = (C.c_double * 3)(*inflate)
+    if host.vigo_host_pcd_load(path.encode(), res, infl, margin, None, 0, dims, origin, C.byref(npts)) != 0:
+        return None
+    buf = np.zeros(dims[0] * dims[1] * dims[2], dtype=np.uint8)
+    assert host.vigo_host_pcd_load(path.encode(), res, infl, margin, buf.ctypes.data_as(C.c_void_p), buf.size, dims, origin, C.byref(npts)) == 0
+    return buf.reshape(dims[0], dims[1], dims[2]), np.array([origin[0], origin[1], origin[2]]), npts.value
+
+
+def test_pcd_reader(host, tmp_path):
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(-2.0, 3.0, size=(500, 3))
+    path = str(tmp_path / "cloud.pcd")
+    with open(path, "w") as f:
+        f.write("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\n"
+                f"WIDTH {len(pts)}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {len(pts)}\nDATA ascii\n")
+        for q in pts:
+            f.write(f"{q[0]:.9g} {q[1]:.9g} {q[2]:.9g}\n")
+    vox, origin, n = pcd_load(host, path, 0.25, inflate=(0.25, 0.0, 0.0))
+    assert n == 500
+    written = np.array([[float(f"{v:.9g}") for v in q] for q in pts])
+    idx = np.floor(written / 0.25).astype(int) - np.round(origin / 0.25).astype(int)
+    occ = np.zeros(vox.shape, dtype=bool)
+    occ[idx[:, 0], idx[:, 1], idx[:, 2]] = True
+    assert np.array_equal((vox & 4) != 0, occ) and not (vox & 2).any()            # no unknown space in a point-cloud map
+    infl = occ.copy()
+    infl[1:] |= occ[:-1]; infl[:-1] |= occ[1:]
+    assert np.array_equal((vox & 1) != 0, infl)
+    # a truncated file (POINTS says more than there are) is refused
+    open(path, "a").close()
+    bad = str(tmp_path / "bad.pcd")
+    open(bad, "w").write(open(path).read().replace("POINTS 500", "POINTS 501"))
+    assert pcd_load(host, bad, 0.25) is None
+    ref = "/root/reference/map/square_static_map.pcd"
+    if os.path.exists(ref):                                                      # the reference's own static map
+        vox, origin, n = pcd_load(host, ref, 0.1)
+        assert n == 102844 and ((vox & 4) != 0).sum() == 102844                  # one point per 0.1 m voxel
 
 
 def test_maze_fixture_is_the_parsed_reference_tree(host):

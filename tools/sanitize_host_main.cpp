@@ -4,11 +4,20 @@
 #include <trajectory_planner/path_search/astarOcc.h>
 #include <cstdio>
 #include <random>
+#include <string>
 int main(int argc, char** argv) {
     using namespace trajPlanner;
     int fails = 0;
     const double inflate[3] = {0.1, 0.1, 0.0};
     for (int i = 1; i < argc; ++i) {
+        const std::string arg = argv[i];
+        if (arg.size() > 4 && arg.substr(arg.size() - 4) == ".pcd") {
+            long long n = 0;
+            auto m = loadPcdAscii(arg, 0.1, inflate, 1, &n);
+            std::printf("%s: %s points %lld dims %d %d %d\n", argv[i], m ? "ok" : "FAILED", n, m ? m->nx() : 0, m ? m->ny() : 0, m ? m->nz() : 0);
+            if (!m) ++fails;
+            continue;
+        }
         BtInfo bi;
         auto m = loadOctomapBt(argv[i], inflate, 2, &bi);
         std::printf("%s: %s nodes %lld/%lld dims %d %d %d\n", argv[i], m ? "ok" : "FAILED", bi.nodes_parsed, bi.nodes_header, m ? m->nx() : 0, m ? m->ny() : 0, m ? m->nz() : 0);

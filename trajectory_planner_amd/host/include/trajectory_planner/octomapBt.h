@@ -32,5 +32,11 @@ struct BtInfo {
  * malformed file. */
 std::shared_ptr<mapManager::occMap> loadOctomapBt(const std::string& path, const double inflate[3], int margin,
                                                   BtInfo* info = nullptr);
+
+/* ASCII .pcd point cloud (the reference's map/square_static_map.pcd, fed to map_manager's static-map
+ * loader there) -> dense map at resolution `res`: a voxel holding a point is occupied, all others are
+ * free and known; same inflation and lattice-aligned origin as above.  nullptr on a malformed file. */
+std::shared_ptr<mapManager::occMap> loadPcdAscii(const std::string& path, double res, const double inflate[3], int margin,
+                                                 long long* pointsRead = nullptr);
 }  // namespace trajPlanner
 #endif

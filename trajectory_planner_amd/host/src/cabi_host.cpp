@@ -34,6 +34,19 @@ int vigo_host_bt_load(const char* path, const double* inflate, int margin, unsig
     return 0;
 }
 
+// dense voxels of an ASCII .pcd at resolution res: first call with out == NULL to get dims/origin/points
+int vigo_host_pcd_load(const char* path, double res, const double* inflate, int margin, unsigned char* out, long long cap, int* dims,
+                       double* origin, long long* points) {
+    auto m = trajPlanner::loadPcdAscii(path, res, inflate, margin, points);
+    if (!m) return -1;
+    dims[0] = m->nx(); dims[1] = m->ny(); dims[2] = m->nz();
+    for (int a = 0; a < 3; ++a) origin[a] = m->origin()(a);
+    if (!out) return 0;
+    if ((long long)m->voxels().size() > cap) return -2;
+    std::memcpy(out, m->voxels().data(), m->voxels().size());
+    return 0;
+}
+
 // min-snap through n_wp waypoints (xyz triples); corridor == NULL: equality-constrained only.
 // coeffs_out: 3 * (n_wp-1) * (deg+1) doubles (x block, y block, z block), knots_out: n_wp doubles.
 int vigo_host_minsnap(int n_wp, const double* wp, int deg, int diff, int cont, double vel, const double* corridor,

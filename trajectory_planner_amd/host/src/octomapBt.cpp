@@ -1,6 +1,7 @@
 // octomapBt.cpp — .bt reader (see the header for the format).  Two passes over the byte stream:
 // bounds, then fill.  Own implementation of the published octomap binary format.
 #include <trajectory_planner/octomapBt.h>
+#include <climits>
 
 #include <algorithm>
 #include <cstdio>
@@ -66,6 +67,31 @@ struct Walker {
 
 }  // namespace
 
+// bit0 = occupied (bit2) dilated by `inflate` metres per axis (separable box dilation)
+static void inflateOccupied(mapManager::occMap& m, const double inflate[3]) {
+    const double res = m.getRes();
+    const int n[3] = {m.nx(), m.ny(), m.nz()};
+    mapManager::occMap* map = &m;
+    const int r[3] = {(int)std::ceil(inflate[0] / res - 1e-9), (int)std::ceil(inflate[1] / res - 1e-9), (int)std::ceil(inflate[2] / res - 1e-9)};
+    std::vector<uint8_t> cur((size_t)n[0] * n[1] * n[2]), nxt(cur.size());
+    for (size_t i = 0; i < cur.size(); ++i) cur[i] = (map->voxels()[i] & 4u) ? 1 : 0;
+    auto idx = [&](int x, int y, int z) { return ((size_t)x * n[1] + y) * n[2] + z; };
+    for (int axis = 0; axis < 3; ++axis) {
+        std::fill(nxt.begin(), nxt.end(), 0);
+        for (int x = 0; x < n[0]; ++x) for (int y = 0; y < n[1]; ++y) for (int z = 0; z < n[2]; ++z) {
+            if (!cur[idx(x, y, z)]) continue;
+            for (int d = -r[axis]; d <= r[axis]; ++d) {
+                int q[3] = {x, y, z};
+                q[axis] += d;
+                if (q[axis] < 0 || q[axis] >= n[axis]) continue;
+                nxt[idx(q[0], q[1], q[2])] = 1;
+            }
+        }
+        cur.swap(nxt);
+    }
+    for (size_t i = 0; i < cur.size(); ++i) if (cur[i]) map->voxels()[i] |= 1u;
+}
+
 std::shared_ptr<mapManager::occMap> loadOctomapBt(const std::string& path, const double inflate[3], int margin, BtInfo* info) {
     std::ifstream f(path, std::ios::binary);
     if (!f) return nullptr;
@@ -116,25 +142,53 @@ std::shared_ptr<mapManager::occMap> loadOctomapBt(const std::string& path, const
     w2.map = map.get();
     for (int a = 0; a < 3; ++a) w2.o[a] = o[a];
     w2.inner(-32768, -32768, -32768, 65536, 0);
-    // inflation of the occupied voxels (bit0), separable box dilation
-    const int r[3] = {(int)std::ceil(inflate[0] / res - 1e-9), (int)std::ceil(inflate[1] / res - 1e-9), (int)std::ceil(inflate[2] / res - 1e-9)};
-    std::vector<uint8_t> cur((size_t)n[0] * n[1] * n[2]), nxt(cur.size());
-    for (size_t i = 0; i < cur.size(); ++i) cur[i] = (map->voxels()[i] & 4u) ? 1 : 0;
-    auto idx = [&](int x, int y, int z) { return ((size_t)x * n[1] + y) * n[2] + z; };
-    for (int axis = 0; axis < 3; ++axis) {
-        std::fill(nxt.begin(), nxt.end(), 0);
-        for (int x = 0; x < n[0]; ++x) for (int y = 0; y < n[1]; ++y) for (int z = 0; z < n[2]; ++z) {
-            if (!cur[idx(x, y, z)]) continue;
-            for (int d = -r[axis]; d <= r[axis]; ++d) {
-                int q[3] = {x, y, z};
-                q[axis] += d;
-                if (q[axis] < 0 || q[axis] >= n[axis]) continue;
-                nxt[idx(q[0], q[1], q[2])] = 1;
-            }
-        }
-        cur.swap(nxt);
+    inflateOccupied(*map, inflate);
+    ++map->version;
+    return map;
+}
+
+// ASCII .pcd (PCL "DATA ascii", FIELDS x y z ...): every point marks its voxel occupied; voxels without a
+// point are free and known (a point cloud map carries no unknown space).  The grid covers the points'
+// bounding box plus `margin` voxels, origin on the res lattice.
+std::shared_ptr<mapManager::occMap> loadPcdAscii(const std::string& path, double res, const double inflate[3], int margin,
+                                                 long long* pointsRead) {
+    std::ifstream f(path);
+    if (!f || !(res > 0)) return nullptr;
+    std::string line;
+    long long declared = -1;
+    bool ascii = false, xyzFirst = false;
+    while (std::getline(f, line)) {
+        if (line.rfind("FIELDS", 0) == 0) xyzFirst = line.find("x y z") != std::string::npos;
+        if (line.rfind("POINTS", 0) == 0) declared = std::atoll(line.c_str() + 6);
+        if (line.rfind("DATA", 0) == 0) { ascii = line.find("ascii") != std::string::npos; break; }
     }
-    for (size_t i = 0; i < cur.size(); ++i) if (cur[i]) map->voxels()[i] |= 1u;
+    if (!ascii || !xyzFirst) return nullptr;
+    std::vector<double> pts;
+    double x, y, z;
+    while (std::getline(f, line)) {
+        if (std::sscanf(line.c_str(), "%lf %lf %lf", &x, &y, &z) == 3 && std::isfinite(x) && std::isfinite(y) && std::isfinite(z)) {
+            pts.push_back(x); pts.push_back(y); pts.push_back(z);
+        }
+    }
+    const long long np = (long long)pts.size() / 3;
+    if (pointsRead) *pointsRead = np;
+    if (np == 0 || (declared >= 0 && np != declared)) return nullptr;
+    long long lo[3] = {LLONG_MAX, LLONG_MAX, LLONG_MAX}, hi[3] = {LLONG_MIN, LLONG_MIN, LLONG_MIN};
+    for (long long i = 0; i < np; ++i)
+        for (int a = 0; a < 3; ++a) {
+            const long long k = (long long)std::floor(pts[3 * i + a] / res);
+            lo[a] = std::min(lo[a], k);
+            hi[a] = std::max(hi[a], k);
+        }
+    long long n[3];
+    for (int a = 0; a < 3; ++a) { lo[a] -= margin; n[a] = hi[a] - lo[a] + 1 + margin; if (n[a] > 4096) return nullptr; }
+    auto map = std::make_shared<mapManager::occMap>((int)n[0], (int)n[1], (int)n[2], Eigen::Vector3d(lo[0] * res, lo[1] * res, lo[2] * res), res);
+    for (long long i = 0; i < np; ++i) {
+        const int ix = (int)((long long)std::floor(pts[3 * i] / res) - lo[0]), iy = (int)((long long)std::floor(pts[3 * i + 1] / res) - lo[1]),
+                  iz = (int)((long long)std::floor(pts[3 * i + 2] / res) - lo[2]);
+        map->at(ix, iy, iz) |= 4u;
+    }
+    inflateOccupied(*map, inflate);
     ++map->version;
     return map;
 }
