@@ -139,6 +139,11 @@ int vigo_set_grid(vigo_handle_t h, int nx, int ny, int nz, const double origin[3
                   double res, const uint8_t* voxels_dev);
 int vigo_set_grid_host(vigo_handle_t h, int nx, int ny, int nz, const double origin[3],
                        double res, const uint8_t* voxels_host);
+/* Inflation of a byte grid on the device, before vigo_set_grid / vigo_pack_grid: bit0 (inflated-occupied)
+ * := OR of bit2 (occupied) over the box |dx| <= rx, |dy| <= ry, |dz| <= rz voxels — what map_manager's
+ * occMap does with the robot size (cfg/bspline_interactive/occupancy_map.yaml:9) before the planner's
+ * isInflatedOccupied queries (BT.cpp:292,412,435).  In place; other bits are kept. */
+int vigo_inflate_grid(vigo_handle_t h, int nx, int ny, int nz, uint8_t* voxels_dev, int rx, int ry, int rz);
 /* Size in bytes of the packed snapshot for a grid of these dims (3 bit planes). */
 size_t vigo_grid_packed_bytes(int nx, int ny, int nz);
 /* Pack a byte grid into the snapshot format into a caller-owned device buffer (so it can

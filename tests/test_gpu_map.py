@@ -143,6 +143,27 @@ def test_corridor_checker_matches_oracle(vigo_handle):
         assert f == flag2.cpu().numpy()[s]
 
 
+def test_inflate_grid_matches_numpy_dilation(vigo_handle):
+    """vigo_inflate_grid: bit0 = box dilation of bit2 (integer/byte work: bit-exact), other bits kept, in place"""
+    v = vigo_handle
+    rng = np.random.default_rng(9)
+    for shape, r in (((37, 50, 19), (2, 1, 0)), ((64, 64, 64), (4, 4, 2)), ((5, 3, 70), (0, 0, 3)), ((16, 16, 16), (0, 0, 0)), ((9, 130, 11), (8, 3, 20))):
+        vox = (rng.random(shape) < 0.02).astype(np.uint8) * 4 + (rng.random(shape) < 0.3).astype(np.uint8) * 2 + (rng.random(shape) < 0.5).astype(np.uint8)
+        occ = (vox & 4) != 0
+        ref = occ.copy()
+        for axis, rr in enumerate(r):
+            acc = ref.copy()
+            for d in range(1, rr + 1):
+                sl_to = [slice(None)] * 3; sl_from = [slice(None)] * 3
+                sl_to[axis] = slice(d, None); sl_from[axis] = slice(None, -d)
+                acc[tuple(sl_to)] |= ref[tuple(sl_from)]
+                acc[tuple(sl_from)] |= ref[tuple(sl_to)]
+            ref = acc
+        got = v.inflate_grid(to_dev(vox, v.device), *r).cpu().numpy()
+        assert np.array_equal((got & 1) != 0, ref), (shape, r)
+        assert np.array_equal(got & 6, vox & 6)
+
+
 @pytest.mark.parametrize("deg", [3, 5, 9])
 def test_corridor_checker_other_polynomial_degrees(vigo_handle, deg):
     """polynomial_degree other than the cfg's 7 (the kernel keeps degree-7 coefficients in registers and

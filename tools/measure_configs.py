@@ -73,6 +73,11 @@ v = Vigo(0)
 vox256 = T(w256.voxels)
 dt = timeit(lambda: v.pack_grid(vox256), 50)
 print(json.dumps({"config": "map: vigo_pack_grid 256^3 byte grid -> 3 bit planes", "ms": dt * 1e3, "GBps_in": 256 ** 3 / dt / 1e9}), flush=True)
+raw = T((w256.voxels & 6))
+dt = timeit(lambda: v.inflate_grid(raw, 4, 4, 2), 30)
+print(json.dumps({"config": "map: vigo_inflate_grid 256^3, robot half size 0.4 x 0.4 x 0.15 m (r = 4, 4, 2 voxels)", "ms": dt * 1e3,
+                  "voxels_per_s": 256 ** 3 / dt, "algorithmic_GBps": 256 ** 3 * 3 / dt / 1e9}), flush=True)
+del raw
 v.set_grid(vox256, w256.origin, w256.res)
 bg = synth.make_bspline_batch(w256, 16384, 32, 99, start_range=8.0, n_obs=2)
 ctrl_g, ooff_g, obs_g = T(bg.ctrl), T(bg.obs_off), T(bg.obs)

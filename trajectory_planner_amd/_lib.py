@@ -63,6 +63,7 @@ PROTOTYPES = {
     "vigo_build_arch": (C.c_char_p, []),
     "vigo_set_grid": (_i, [_vp, _i, _i, _i, _d3, _d, _vp]),
     "vigo_set_grid_host": (_i, [_vp, _i, _i, _i, _d3, _d, _vp]),
+    "vigo_inflate_grid": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i]),
     "vigo_grid_packed_bytes": (C.c_size_t, [_i, _i, _i]),
     "vigo_pack_grid": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "vigo_set_grid_packed": (_i, [_vp, _i, _i, _i, _d3, _d, _vp]),

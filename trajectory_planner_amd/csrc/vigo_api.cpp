@@ -232,6 +232,18 @@ int vigo_pack_grid(vigo_handle_t h, int nx, int ny, int nz, const uint8_t* voxel
     return VIGO_OK;
 }
 
+int vigo_inflate_grid(vigo_handle_t h, int nx, int ny, int nz, uint8_t* voxels_dev, int rx, int ry, int rz) {
+    if (!h || !voxels_dev || nx <= 0 || ny <= 0 || nz <= 0 || rx < 0 || ry < 0 || rz < 0 || (size_t)nx * ny * nz > ((size_t)1 << 31))
+        return fail(h, VIGO_ERR_INVALID_ARG, "vigo_inflate_grid: bad argument");
+    if (rz > 31) return fail(h, VIGO_ERR_UNSUPPORTED, "vigo_inflate_grid: rz > 31 voxels");
+    const size_t nw = (size_t)nx * ny * ((nz + 31) / 32);
+    int rc = ensure_scratch(h, 2 * nw * sizeof(uint32_t));
+    if (rc) return rc;
+    uint32_t* t = static_cast<uint32_t*>(h->scratch);
+    VIGO_HIP(h, (hipError_t)vigo::launch_inflate(h->stream, nx, ny, nz, voxels_dev, t, t + nw, rx, ry, rz));
+    return VIGO_OK;
+}
+
 int vigo_set_grid(vigo_handle_t h, int nx, int ny, int nz, const double origin[3], double res, const uint8_t* voxels_dev) {
     if (!h || !voxels_dev || !origin || nx <= 0 || ny <= 0 || nz <= 0 || !(res > 0)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_grid: bad argument");
     int rc = ensure_grid_storage(h, nx, ny, nz);

@@ -82,6 +82,7 @@ int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, const 
 size_t optimize_lds_requirement(int N, int mem_size, int precision);
 
 int launch_pack_grid(hipStream_t s, int nx, int ny, int nz, const uint8_t* vox, uint32_t* packed);
+int launch_inflate(hipStream_t s, int nx, int ny, int nz, uint8_t* vox, uint32_t* planeA, uint32_t* planeB, int rx, int ry, int rz);
 int launch_query_points(hipStream_t s, const GridView& g, int which, int64_t Q, const double* pts,
                         int pt_stride, uint8_t* out);
 int launch_bspline_eval(hipStream_t s, int B, int N, const double* ctrl, double ts_ctrl, int deriv,

@@ -51,6 +51,85 @@ __global__ void k_pack_grid(int nx, int ny, int nz, int nzw, const uint8_t* __re
     packed[2 * plane_words + wi] = b2;
 }
 
+// ---- inflation on bit planes -----------------------------------------------------------------
+// bit0 of the byte grid := box dilation of bit2 (map_manager inflates the occupied voxels by the robot
+// size).  The occupied bit is packed to one bit per voxel (z fastest, 32 voxels per
+// word — the snapshot's plane format), dilated there — along z with shifts and carries between
+// neighbouring words, along y and x by OR-ing whole words — and merged back: 3 bytes of HBM traffic
+// per voxel instead of 2 per voxel and pass (a 256^3 plane is 2 MiB: the three dilation passes never
+// leave the L2).
+__global__ void k_pack_bit(int nz, int nzw, size_t n_words, int bit, const uint8_t* __restrict__ vox, uint32_t* __restrict__ plane) {
+    const size_t wi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= n_words) return;
+    const size_t col = wi / nzw;
+    const int w = (int)(wi % nzw);
+    const uint8_t* src = vox + col * nz + (size_t)w * 32;
+    const int cnt = min(32, nz - w * 32);
+    uint32_t b = 0;
+    if (cnt == 32 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {   // 32 voxels = two 16-byte loads
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        const uint4 q[2] = {s4[0], s4[1]};
+        const uint32_t* wds = reinterpret_cast<const uint32_t*>(q);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b |= ((wds[i] >> (8 * j + bit)) & 1u) << (4 * i + j);
+    } else {
+        for (int i = 0; i < cnt; ++i) b |= (uint32_t)((src[i] >> bit) & 1u) << i;
+    }
+    plane[wi] = b;
+}
+// z: out word = OR over |d| <= r of the row shifted by d bits (r <= 31: one neighbour word each side)
+__global__ void k_dilate_bits_z(int nz, int nzw, size_t n_words, int r, const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+    const size_t wi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= n_words) return;
+    const int w = (int)(wi % nzw);
+    const uint64_t lo = w > 0 ? in[wi - 1] : 0u, mid = in[wi], hi = w + 1 < nzw ? in[wi + 1] : 0u;
+    uint32_t acc = (uint32_t)mid;
+    for (int d = 1; d <= r; ++d) {
+        acc |= (uint32_t)(((mid << 32 | lo) >> (32 - d)) & 0xffffffffu);   // voxels z - d land on z
+        acc |= (uint32_t)(((hi << 32 | mid) >> d) & 0xffffffffu);          // voxels z + d land on z
+    }
+    const int valid = nz - 32 * w;                                          // bits past nz stay clear
+    if (valid < 32) acc &= (1u << valid) - 1u;
+    out[wi] = acc;
+}
+// y (stride nzw words, length ny) or x (stride ny * nzw, length nx): OR of whole words
+__global__ void k_dilate_bits_rows(size_t n_words, size_t stride, int len, int r, const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+    const size_t wi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= n_words) return;
+    const int c = (int)((wi / stride) % (size_t)len);
+    const int lo = c - r < 0 ? -c : -r, hi = c + r >= len ? len - 1 - c : r;
+    uint32_t acc = 0;
+    for (int d = lo; d <= hi; ++d) acc |= in[(ptrdiff_t)wi + (ptrdiff_t)d * (ptrdiff_t)stride];
+    out[wi] = acc;
+}
+// one plane word (32 voxels) per thread: bit0 of the 32 bytes from the word's bits
+__global__ void k_merge_bit0(int nz, int nzw, size_t n_words, const uint32_t* __restrict__ plane, uint8_t* __restrict__ vox) {
+    const size_t wi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= n_words) return;
+    const size_t col = wi / nzw;
+    const int w = (int)(wi % nzw);
+    uint8_t* dst = vox + col * nz + (size_t)w * 32;
+    const int cnt = min(32, nz - w * 32);
+    const uint32_t bits = plane[wi];
+    if (cnt == 32 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        uint4 q[2] = {d4[0], d4[1]};
+        uint32_t* wds = reinterpret_cast<uint32_t*>(q);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t nib = (bits >> (4 * i)) & 0xFu;
+            const uint32_t spread = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);   // one bit per byte
+            wds[i] = (wds[i] & 0xFEFEFEFEu) | spread;
+        }
+        d4[0] = q[0];
+        d4[1] = q[1];
+    } else {
+        for (int i = 0; i < cnt; ++i) dst[i] = (uint8_t)((dst[i] & ~1u) | ((bits >> i) & 1u));
+    }
+}
+
 __global__ void k_query_points(GridView g, int plane, int64_t Q, const double* __restrict__ pts,
                                int stride, uint8_t* __restrict__ out) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -152,6 +231,18 @@ int launch_pack_grid(hipStream_t s, int nx, int ny, int nz, const uint8_t* vox, 
     const int block = 256;
     const size_t grid = (words + block - 1) / block;
     hipLaunchKernelGGL(k_pack_grid, dim3((unsigned)grid), dim3(block), 0, s, nx, ny, nz, nzw, vox, packed);
+    return (int)hipGetLastError();
+}
+
+int launch_inflate(hipStream_t s, int nx, int ny, int nz, uint8_t* vox, uint32_t* planeA, uint32_t* planeB, int rx, int ry, int rz) {
+    const int nzw = (nz + 31) / 32;
+    const size_t nw = (size_t)nx * ny * nzw;
+    const unsigned gw = (unsigned)((nw + 255) / 256);
+    hipLaunchKernelGGL(k_pack_bit, dim3(gw), dim3(256), 0, s, nz, nzw, nw, 2, vox, planeA);
+    hipLaunchKernelGGL(k_dilate_bits_z, dim3(gw), dim3(256), 0, s, nz, nzw, nw, rz, planeA, planeB);
+    hipLaunchKernelGGL(k_dilate_bits_rows, dim3(gw), dim3(256), 0, s, nw, (size_t)nzw, ny, ry, planeB, planeA);
+    hipLaunchKernelGGL(k_dilate_bits_rows, dim3(gw), dim3(256), 0, s, nw, (size_t)ny * nzw, nx, rx, planeA, planeB);
+    hipLaunchKernelGGL(k_merge_bit0, dim3(gw), dim3(256), 0, s, nz, nzw, nw, planeB, vox);
     return (int)hipGetLastError();
 }
 

@@ -131,6 +131,13 @@ class Vigo:
                                             _ptr(voxels, torch.uint8, "voxels", self.device)), "vigo_set_grid")
         self._grid_meta = (nx, ny, nz, tuple(float(v) for v in origin), float(res))
 
+    def inflate_grid(self, voxels: torch.Tensor, rx: int, ry: int, rz: int) -> torch.Tensor:
+        """in place: bit0 := OR of bit2 over the (2rx+1)(2ry+1)(2rz+1) voxel box"""
+        nx, ny, nz = voxels.shape
+        self._check(self._lib.vigo_inflate_grid(self._h, nx, ny, nz, _ptr(voxels, torch.uint8, "voxels", self.device), rx, ry, rz),
+                    "vigo_inflate_grid")
+        return voxels
+
     def pack_grid(self, voxels: torch.Tensor) -> torch.Tensor:
         """Pack a byte grid into the snapshot format (int32 tensor) for an RCCL broadcast."""
         nx, ny, nz = voxels.shape
