@@ -1,0 +1,61 @@
+"""Randomised parity sweep of vigo_corridor_check and vigo_box_collision_points against the oracle (bit for bit):
+collision boxes from 0.1 to 1.3 m per axis, map_resolution 0.05-0.45 (fast per-axis path and the generic walk), grid
+resolutions 0.1 / 0.05, polynomial degrees 3-9, ragged sample counts, metric bounds inside and outside the grid.
+Not part of the test suite; run on the GPU box:  python tools/fuzz_corridor.py [cases] [seed]"""
+import ctypes as C, json, os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np, torch
+import oracle_lib as ol
+from gpu_util import to_dev
+from trajectory_planner_amd import synth
+from trajectory_planner_amd.vigo import Vigo
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
+O = ol.oracle()
+bad = 0
+t0 = time.time()
+for case in range(cases):
+    res = float(rng.choice([0.1, 0.05]))
+    n = int(rng.choice([48, 96]))
+    vox = np.zeros((n, n, 24), dtype=np.uint8)
+    for _ in range(int(rng.integers(5, 40))):
+        c = rng.integers(2, n - 2, size=2); s = rng.integers(1, 5, size=2)
+        vox[max(c[0] - s[0], 0):c[0] + s[0], max(c[1] - s[1], 0):c[1] + s[1], 0:rng.integers(4, 24)] |= 4
+    unk = rng.random((n // 8, n // 8, 3)) < 0.08
+    vox[np.repeat(np.repeat(np.repeat(unk, 8, 0), 8, 1), 8, 2)] |= 2
+    origin = np.array([-n * res / 2, -n * res / 2, -0.5]).round(6)
+    origin = np.round(origin / res) * res                                   # octomap key lattice
+    world = synth.World(vox, origin, res, np.zeros((0, 6)))
+    v = Vigo(0)
+    v.set_grid(to_dev(vox, v.device), origin, res)
+    g, keep = ol.make_grid(world)
+    if rng.random() < 0.3:
+        bmin = origin + rng.uniform(0.2, 1.0, 3) * [1, 1, 0.2]; bmax = origin + np.array(vox.shape) * res - rng.uniform(0.2, 1.0, 3) * [1, 1, 0.2]
+        v.set_metric_bounds(bmin, bmax); g.bmin[:] = list(bmin); g.bmax[:] = list(bmax)
+    box = rng.uniform(0.1, 1.3, size=3) * [1, 1, 0.5]
+    map_res = float(rng.choice([0.05, 0.1, 0.2, 0.25, 0.45]))
+    deg = int(rng.integers(3, 10))
+    half = n * res / 2
+    S = 24
+    coeffs, n_samp, delT, dur = synth.make_corridor_segments(int(rng.integers(1 << 30)), S, deg=deg, extent_lo=(-half * 0.9, -half * 0.9, 0.0),
+                                                             extent_hi=(half * 0.9, half * 0.9, 1.6), n_samples=int(rng.integers(50, 1500)))
+    n_samp[:4] = [0, 1, 17, 33]
+    flag, first, count = (x.cpu().numpy() for x in v.corridor_check(to_dev(coeffs, v.device), to_dev(n_samp, v.device), to_dev(delT, v.device), box, map_res))
+    ok = True
+    for s in range(S):
+        fi, cn = C.c_int(), C.c_int()
+        c = np.ascontiguousarray(coeffs[s])
+        f = O.vgo_corridor_check_segment(C.byref(g), deg, ol._d(c), int(n_samp[s]), float(delT[s]), ol._d(box), map_res, C.byref(fi), C.byref(cn))
+        ok = ok and (f, fi.value, cn.value) == (flag[s], first[s], count[s])
+    # the per-pose sweep on random poses
+    pts = rng.uniform(-half * 1.1, half * 1.1, size=(400, 3)) * [1, 1, 0.2] + [0, 0, 0.8]
+    got = v.box_collision_points(to_dev(pts, v.device), box, map_res).cpu().numpy()
+    for i in range(len(pts)):
+        ok = ok and got[i] == O.vgo_box_collision(C.byref(g), C.c_float(pts[i, 0]), C.c_float(pts[i, 1]), C.c_float(pts[i, 2]), ol._d(box), C.c_double(map_res))
+    if not ok:
+        bad += 1
+        print(json.dumps({"MISMATCH": case, "res": res, "box": box.tolist(), "map_res": map_res, "deg": deg}), flush=True)
+    v.close()
+print(json.dumps({"cases": cases, "mismatches": bad, "seconds": time.time() - t0}))
+sys.exit(1 if bad else 0)
