@@ -51,25 +51,49 @@ int check_solve_args(vigo_handle_t h, int B, int N, const void* ctrl) {
     return VIGO_OK;
 }
 
-// accumulated sample times of `for (t = 0; t <= tmax; t += dt)` (BT.h:313, BT.cpp:1442):
-// computed sequentially on the host exactly like the reference so the sample count and every
-// t_k carry the reference's rounding, then uploaded (a few hundred doubles).
+// Sample times of `for (t = 0; t <= tmax; t += dt)` (BT.h:313, :347): t_k is the k-fold floating point
+// accumulation, reproduced exactly by vigo::accumulated_time (closed form per binade).  The sample count T is
+// found on the host by bisection over that closed form (monotone in k), the table is filled by a device kernel
+// and cached in the handle per (dt, tmax): the gates run without a host round trip.
 int upload_sample_times(vigo_handle_t h, double tmax, double dt, int* out_T, const double** out_dev) {
     if (!(dt > 0.0)) return fail(h, VIGO_ERR_INVALID_ARG, "dt must be > 0");
-    std::vector<double> times;
-    for (double t = 0; t <= tmax; t += dt) {
-        times.push_back(t);
-        if (times.size() > (size_t)1 << 24) return fail(h, VIGO_ERR_INVALID_ARG, "too many samples");
+    if (h->times_T >= 0 && h->times_dt == dt && h->times_tmax == tmax) {
+        if (h->times_stream != h->stream) {            // filled on another stream: make sure it has landed
+            VIGO_HIP(h, hipStreamSynchronize(h->times_stream));
+            h->times_stream = h->stream;
+        }
+        *out_T = h->times_T;
+        *out_dev = h->times_dev;
+        return VIGO_OK;
     }
-    int rc = ensure_scratch(h, times.size() * sizeof(double) + 64);
-    if (rc) return rc;
-    if (!times.empty())
-        VIGO_HIP(h, hipMemcpyAsync(h->scratch, times.data(), times.size() * sizeof(double),
-                                   hipMemcpyHostToDevice, h->stream));
-    // the vector dies at return: make sure the copy has consumed it
-    VIGO_HIP(h, hipStreamSynchronize(h->stream));
-    *out_T = (int)times.size();
-    *out_dev = static_cast<const double*>(h->scratch);
+    int T = 0;
+    if (tmax >= 0.0) {
+        const int64_t cap = (int64_t)1 << 24;
+        if (vigo::accumulated_time(dt, cap) <= tmax) return fail(h, VIGO_ERR_INVALID_ARG, "too many samples");
+        int64_t lo = 0, hi = cap;                       // t_lo <= tmax < t_hi
+        while (hi - lo > 1) {
+            const int64_t mid = lo + (hi - lo) / 2;
+            if (vigo::accumulated_time(dt, mid) <= tmax) lo = mid; else hi = mid;
+        }
+        T = (int)hi;                                    // samples k = 0 .. lo
+    }
+    if ((size_t)T > h->times_cap) {
+        if (h->times_dev) (void)hipFree(h->times_dev);
+        h->times_dev = nullptr;
+        h->times_cap = 0;
+        h->times_T = -1;
+        const size_t want = (size_t)T + 64;
+        VIGO_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->times_dev), want * sizeof(double)));
+        h->times_cap = want;
+    }
+    h->times_T = -1;
+    VIGO_HIP(h, (hipError_t)vigo::launch_fill_sample_times(h->stream, dt, T, h->times_dev));
+    h->times_dt = dt;
+    h->times_tmax = tmax;
+    h->times_T = T;
+    h->times_stream = h->stream;
+    *out_T = T;
+    *out_dev = h->times_dev;
     return VIGO_OK;
 }
 
@@ -168,6 +192,7 @@ int vigo_destroy(vigo_handle_t h) {
     if (h->grid_planes) (void)hipFree(h->grid_planes);
     if (h->esdf) (void)hipFree(h->esdf);
     if (h->fit_pinvT) (void)hipFree(h->fit_pinvT);
+    if (h->times_dev) (void)hipFree(h->times_dev);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->dc_dev) (void)hipFree(h->dc_dev);
     delete h;
@@ -348,6 +373,7 @@ int vigo_bspline_fit(vigo_handle_t h, int B, int K, double ts, const double* poi
         const size_t need = vigo::fit_pinv_doubles(K);
         if (need > h->fit_capacity) {
             if (h->fit_pinvT) (void)hipFree(h->fit_pinvT);
+    if (h->times_dev) (void)hipFree(h->times_dev);
             h->fit_pinvT = nullptr;
             h->fit_capacity = 0;
             h->fit_K = 0;

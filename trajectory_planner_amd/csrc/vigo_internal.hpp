@@ -93,6 +93,7 @@ int launch_traj_collision(hipStream_t s, const GridView& g, int B, int N, const 
 int launch_traj_dynamic_collision(hipStream_t s, int B, int N, const double* ctrl, double ts_ctrl,
                                   int T, const double* times, const int32_t* obs_off,
                                   const double* obs, int n_obs_shared, uint8_t* out_flag);
+int launch_fill_sample_times(hipStream_t s, double dt, int T, double* times);
 int launch_ctrl_occupancy(hipStream_t s, const GridView& g, int B, int N, const double* ctrl,
                           uint8_t* out_pt, uint8_t* out_line);
 int launch_corridor_check(hipStream_t s, const GridView& g, int S, int deg, const double* coeffs,
@@ -141,6 +142,12 @@ struct vigo_context {
     size_t fit_capacity = 0;   // doubles
     int fit_K = 0;
     double fit_ts = 0.0;
+    // sample clock of the gates, cached per (dt, tmax): filled on the device, no host round trip per call
+    double* times_dev = nullptr;
+    size_t times_cap = 0;      // doubles
+    double times_dt = -1.0, times_tmax = -1.0;
+    int times_T = -1;
+    hipStream_t times_stream = nullptr;
     // scratch (sample-time tables, corridor checkpoints, staging of *_host calls)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;

@@ -7,6 +7,7 @@
 // ~120-240 lookups scattered over a 7 m path, fewer words than staging its bounding volume in
 // LDS would read.  The LDS-tiled path is the corridor checker (vigo_corridor.hip), where one
 // segment makes ~10^5 lookups inside a small volume.
+#include "vigo_exact_time.hpp"
 #include "vigo_grid.hpp"
 
 namespace vigo {
@@ -151,6 +152,13 @@ __global__ void k_bspline_eval(int B, int N, const double* __restrict__ ctrl, do
 }
 
 // one 64-lane wave per trajectory; lanes stride over the samples; first hit = wave min
+// t_k of the reference's sample loop `for (t = 0; t <= tmax; t += dt)` (BT.h:313, :347), k = 0 .. T-1, by the
+// closed form of vigo_exact_time.hpp — filled once per (dt, tmax) and cached in the handle
+__global__ void k_fill_sample_times(double dt, int T, double* __restrict__ times) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < T) times[k] = accumulated_time(dt, k);
+}
+
 __global__ void __launch_bounds__(64) k_traj_collision(GridView g, int B, int N, const double* __restrict__ ctrl,
                                                        double ts, int T, const double* __restrict__ times,
                                                        uint8_t* __restrict__ out_flag, int32_t* __restrict__ out_first) {
@@ -278,6 +286,12 @@ int launch_traj_dynamic_collision(hipStream_t s, int B, int N, const double* ctr
     if (B <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_traj_dynamic_collision, dim3(B), dim3(64), 0, s, B, N, ctrl, ts_ctrl, T, times, obs_off, obs,
                        n_obs_shared, out_flag);
+    return (int)hipGetLastError();
+}
+
+int launch_fill_sample_times(hipStream_t s, double dt, int T, double* times) {
+    if (T <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_sample_times, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, dt, T, times);
     return (int)hipGetLastError();
 }
 
