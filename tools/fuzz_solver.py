@@ -25,6 +25,7 @@ for case in range(cases):
     P.plan_in_z = int(rng.integers(0, 2))
     P.uncertain_factor = float(rng.choice([1.0, 1.5]))
     n_obs = int(rng.choice([0, 0, 1, 3, 17]))
+    P.pred_horizon = float(rng.choice([2.0, 2.0, 0.5, 3.0, 12.0]))   # 11 / 3 / 16 / 61 predicted steps per obstacle
     fast = bool(rng.integers(0, 2))
     b = synth.make_bspline_batch(world, B, N, int(rng.integers(1 << 30)), start_range=3.0, n_obs=n_obs)
     w = np.ones((B, 4)) * rng.choice([1.0, 2.0, 4.0], size=(B, 4))

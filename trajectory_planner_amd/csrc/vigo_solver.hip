@@ -31,8 +31,13 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kMaxMem = VIGO_MAX_MEM_SIZE;
-constexpr int kObsCache = 16;  // dynamic obstacles per trajectory staged in LDS by the solve kernel
-constexpr int kObsRec = 6;     // doubles per staged obstacle (5 used, 48-byte records)
+// Dynamic-obstacle table of the solve kernel: per trajectory, {predicted x, predicted y, threshold}
+// of up to kObsTabEntries (obstacle, predicted step) pairs plus the obstacles' sizes, staged in LDS
+// once per solve (they do not depend on the control points).  Sized so that the N = 32 and N = 64
+// shapes keep four waves per CU (<= 40 KiB per wave).
+constexpr int kObsTabObs = 16;
+template <int GROUP> constexpr int kObsTabEntries = GROUP == 32 ? 96 : 44;
+template <int GROUP> constexpr int kObsTabDoubles = 3 * kObsTabEntries<GROUP> + kObsTabObs;
 
 // reference status codes, LB:20-80
 enum : int {
@@ -249,11 +254,13 @@ struct LaneProblem {
     bool gqu[kGuideDim];
     int o_begin, o_end;       // this trajectory's obstacles
     const double* obs;
-    // (whole-solve kernel) the first kObsCache obstacles of this trajectory as {pos.x, pos.y,
-    // vel.x, vel.y, size} records in LDS, staged once per solve: they never change, and a global
-    // load per obstacle per evaluation is a ~2 us round trip on the critical path
-    const double* obs_cache;
-    int o_cached;
+    // (whole-solve kernel) the first o_tab obstacles of this trajectory as a table in LDS:
+    // obs_tab[3 * (j * o_steps + s)] = {x, y, threshold} at predicted step n = 2 s, then the sizes
+    // at obs_tab[3 * entries + j].  Staged once per solve: nothing in it depends on the control
+    // points, and a global load per obstacle per evaluation is a ~2 us round trip on the critical path
+    const double* obs_tab;
+    const double* obs_size;
+    int o_tab, o_steps;
     double w[4];
 };
 
@@ -317,6 +324,28 @@ __device__ __forceinline__ void obstacle_term(const DevConst& K, const T (&c)[3]
             // diff.z = 0 (BT.cpp:1022): for a finite positive |diff| the z term is k * (+0) = +-0 and
             // leaves the +0 (or NaN) accumulator as it is, so its fp64 division is only issued in
             // the degenerate cases (control point exactly on the predicted centre, NaN/inf input)
+            if (__builtin_expect(!(nrm > T(0) && nrm < (T)INFINITY), 0)) Go[2] += k * (dz / nrm);
+        }
+    }
+}
+
+// The same term with the per-step operands {px, py, thr} read from the solve kernel's LDS table
+// (they were computed there by the expressions above, so the bits are the same).
+template <typename T>
+__device__ __forceinline__ void obstacle_term_tab(const DevConst& K, const T (&c)[3], const double* tab, int steps,
+                                                  T size, double& co, T (&Go)[3]) {
+    const T oa = (T)K.oa, ob = (T)K.ob, oc = (T)K.oc;
+    for (int s = 0; s < steps; ++s) {
+        const T px = (T)tab[3 * s + 0], py = (T)tab[3 * s + 1], thr = (T)tab[3 * s + 2];
+        const T dx = c[0] - px, dy = c[1] - py, dz = T(0.0);
+        const T nrm = sqrt((dx * dx + dy * dy) + dz * dz);
+        const T e = thr - (nrm - size);
+        if (e > T(0)) {
+            const bool cubic = e <= thr;
+            const T ct = cubic ? (e * e) * e : (oa * (e * e) + ob * e) + oc;
+            const T k = cubic ? T(-3.0) * (e * e) : -((T(2) * oa) * e + ob);
+            co += (double)ct;
+            Go[0] += k * (dx / nrm); Go[1] += k * (dy / nrm);
             if (__builtin_expect(!(nrm > T(0) && nrm < (T)INFINITY), 0)) Go[2] += k * (dz / nrm);
         }
     }
@@ -471,12 +500,10 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
             if (!Q.interior[q]) continue;
             double co = 0.0;
             // the obstacles staged in LDS by the solve kernel first (same order as the list) ...
-            for (int j = 0; j < Q.o_cached; ++j) {
-                const double* oc = Q.obs_cache + kObsRec * j;
-                obstacle_term<T>(K, c[q], (T)oc[0], (T)oc[1], (T)oc[2], (T)oc[3], (T)oc[4], co, Go[q]);
-            }
+            for (int j = 0; j < Q.o_tab; ++j)
+                obstacle_term_tab<T>(K, c[q], Q.obs_tab + 3 * j * Q.o_steps, Q.o_steps, (T)Q.obs_size[j], co, Go[q]);
             // ... then the rest (all of them for the standalone cost/gradient kernel) from HBM/L2
-            for (int j = Q.o_begin + Q.o_cached; j < Q.o_end; ++j) {
+            for (int j = Q.o_begin + Q.o_tab; j < Q.o_end; ++j) {
                 const double* o = Q.obs + 9 * (size_t)j;
                 const T hx = (T)o[6] / 2, hy = (T)o[7] / 2;
                 obstacle_term<T>(K, c[q], (T)o[0], (T)o[1], (T)o[3], (T)o[4], sqrt(hx * hx + hy * hy), co, Go[q]);
@@ -544,8 +571,8 @@ __device__ __forceinline__ void load_problem(const SolveArgs& A, const DevConst&
         }
     }
     Q.obs = A.obs;
-    Q.obs_cache = nullptr;
-    Q.o_cached = 0;
+    Q.obs_tab = Q.obs_size = nullptr;
+    Q.o_tab = Q.o_steps = 0;
     if (A.obs_off) {
         Q.o_begin = A.obs_off[b];
         Q.o_end = A.obs_off[b + 1];
@@ -779,19 +806,30 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
     YS* ys_l = reinterpret_cast<YS*>(ys_tab) + grp;
     double* al_l = ys_tab + 2 * (size_t)m * TPB + grp;
     if (A.obs) {
-        // stage this trajectory's obstacles (BT.cpp:1011-1015 operands) once; size in T arithmetic
-        double* oc = ys_tab + 3 * (size_t)m * TPB + (size_t)grp * kObsCache * kObsRec;
+        // stage this trajectory's obstacles once: the predicted positions and thresholds of
+        // BT.cpp:1011-1020 by the expressions of obstacle_term(), sizes in T arithmetic
+        constexpr int kEnt = kObsTabEntries<GROUP>;
+        double* tab = ys_tab + 3 * (size_t)m * TPB + (size_t)grp * kObsTabDoubles<GROUP>;
         const int cnt = Q.o_end - Q.o_begin;
-        Q.o_cached = cnt < kObsCache ? cnt : kObsCache;
-        Q.obs_cache = oc;
-        for (int j = lane % GROUP; j < Q.o_cached; j += GROUP) {
+        const int steps = K.pred_num / 2 + 1;
+        int fit = kEnt / steps;
+        if (fit > kObsTabObs) fit = kObsTabObs;
+        Q.o_tab = cnt < fit ? cnt : fit;
+        Q.o_steps = steps;
+        Q.obs_tab = tab;
+        Q.obs_size = tab + 3 * kEnt;
+        for (int e = lane % GROUP; e < Q.o_tab * steps; e += GROUP) {
+            const int j = e / steps, n = 2 * (e - j * steps);
+            const double* o = A.obs + 9 * (size_t)(Q.o_begin + j);
+            const T tn = (T)((double)n * K.ts);
+            tab[3 * e + 0] = (double)((T)o[0] + tn * (T)o[3]);
+            tab[3 * e + 1] = (double)((T)o[1] + tn * (T)o[4]);
+            tab[3 * e + 2] = (double)((T(1) - (T)(n / K.pred_num) * T(0.2)) * (T)K.thr_dyn);
+        }
+        for (int j = lane % GROUP; j < Q.o_tab; j += GROUP) {
             const double* o = A.obs + 9 * (size_t)(Q.o_begin + j);
             const T hx = (T)o[6] / 2, hy = (T)o[7] / 2;
-            oc[kObsRec * j + 0] = (double)(T)o[0];
-            oc[kObsRec * j + 1] = (double)(T)o[1];
-            oc[kObsRec * j + 2] = (double)(T)o[3];
-            oc[kObsRec * j + 3] = (double)(T)o[4];
-            oc[kObsRec * j + 4] = (double)(T)sqrt(hx * hx + hy * hy);
+            tab[3 * kEnt + j] = (double)(T)sqrt(hx * hx + hy * hy);
         }
         __syncthreads();  // one wave per workgroup: orders the staging writes before the lanes' reads
     }
@@ -1171,7 +1209,7 @@ size_t optimize_lds_bytes(int N, int m, int ppl, bool with_obstacles) {
     size_t h = (size_t)ms * TPB * (N - 6) * sizeof(HPair<T>);
     h = (h + 15) & ~(size_t)15;
     h += 3 * (size_t)m * TPB * sizeof(double);   // {ys, 1/ys} per slot + the alphas
-    if (with_obstacles) h += (size_t)TPB * kObsCache * kObsRec * sizeof(double);
+    if (with_obstacles) h += (size_t)TPB * kObsTabDoubles<GROUP> * sizeof(double);
     return h;
 }
 
