@@ -950,12 +950,17 @@ std::vector<bool> bsplineTraj::makePlanBatch(const std::vector<bsplineTraj*>& pl
     const double tp1 = wallSeconds();
     // step 4: rebound loops.  The 30 ms budget of BT.cpp:633 is per makePlan() call in the
     // reference; a batch keeps it per round so one slow planner cannot starve the others.
+    const bool timing = getenv("VIGO_FACADE_TIMING") != nullptr;
+    double tr0 = wallSeconds();
     solveBatch(active);
+    if (timing) cout << "[BsplineTraj]:   first solve of " << active.size() << ": " << (wallSeconds() - tr0) * 1e3 << " ms" << endl;
     const double t0 = wallSeconds();
     const double budget = 0.03 * std::max<size_t>(1, active.size());
     while (!active.empty()) {
         std::vector<uint8_t> col, dyn;
+        tr0 = wallSeconds();
         gateBatch(active, col, dyn);
+        const double tr1 = wallSeconds();
         const bool timedOut = wallSeconds() - t0 > budget;
         std::vector<bsplineTraj*> next, solve;
         std::vector<size_t> nextIdx;
@@ -973,7 +978,11 @@ std::vector<bool> bsplineTraj::makePlanBatch(const std::vector<bsplineTraj*>& pl
                 if (r.needOptimize) solve.push_back(active[a]);
             }
         }
+        const double tr2 = wallSeconds();
         solveBatch(solve);
+        if (timing)
+            cout << "[BsplineTraj]:   round of " << active.size() << ": gates " << (tr1 - tr0) * 1e3 << " ms, rebound step " << (tr2 - tr1) * 1e3
+                 << " ms, solve of " << solve.size() << " " << (wallSeconds() - tr2) * 1e3 << " ms" << endl;
         active.swap(next);
         activeIdx.swap(nextIdx);
     }
