@@ -1054,7 +1054,11 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
             // add and a wrap per fetch instead of slot arithmetic and two quarter-rate multiplies
             constexpr int kRing = kMaxMem - 2;
             const int stepB = ROW * (int)sizeof(HPair<T>), stepY = TPB * (int)sizeof(YS);
-            int curB = last * stepB, curY = last * stepY;   // slot of the age-2 pair
+            // (the slot index is the same in every live lane — all trajectories of a wave are in the
+            // same iteration — and is taken through an SGPR so the ring walk is scalar work; the caller
+            // checks the uniformity)
+            const int lastU = STEADY ? __builtin_amdgcn_readfirstlane(last) : 0;
+            int curB = lastU * stepB, curY = lastU * stepY;   // slot of the age-2 pair
             auto ring_fetch = [&](T (&s_)[PPL][3], T (&y_)[PPL][3], YS& ys_) {
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) {
@@ -1144,7 +1148,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
                 for (int a = 0; a < 3; ++a) bad |= !(d[q][a] == d[q][a]);
             return bad;
         };
-        if (VIGO_TWOLOOP_STEADY && PPL == 1 && bound == kMaxMem) {
+        if (VIGO_TWOLOOP_STEADY && PPL == 1 && bound == kMaxMem && !__any(last != __builtin_amdgcn_readfirstlane(last))) {
             if (__any(two_loop(std::true_type{}))) {
                 // a dividend outside the range Markstein's sequence is proven for (or a NaN): the same
                 // recursion again from d = -g on the general path, which divides for real
