@@ -117,6 +117,14 @@ def test_infeasible_corridor_and_degenerate_paths_are_reported(vigo_handle):
     wp = np.array([[[0, 0, 1], [2, 0.2, 1], [3, 2.5, 1.2], [5.5, 3, 1]]], dtype=float)
     _, _, status = v.minsnap(to_dev(wp, v.device), to_dev(np.full((1, 3), 0.08), v.device))
     assert status.cpu().numpy()[0] == -2                              # same case as tests/test_host_plumbing.py
+    # found by tools/fuzz_minsnap.py: infeasible by 4.4 mm on x (LP check), but rounding hid the vanishing
+    # step direction and the active-set loop "finished" — caught by the final verification of every box
+    wp2 = np.array([[[4.72784813, 3.33450493, 1.12281751], [6.43095329, 3.12257235, 0.36993818], [6.41296218, 2.10602218, 0.26463582],
+                     [7.11605367, 2.86112028, 0.1304162], [9.32719285, 4.65800487, 0.54451007], [10.66551612, 5.68254561, 0.74141194]]])
+    cor2 = np.array([[0.20920871, 0.33720714, 0.3973849, 0.20369017, 0.09165364]])
+    _, _, status = v.minsnap(to_dev(wp2, v.device), to_dev(cor2, v.device), corridor_res=4.0)
+    assert status.cpu().numpy()[0] == -2
+    assert host_solve(wp2[0], cor2[0], 4.0)[0] != 0
     dup = wp.copy()
     dup[0, 2] = dup[0, 1]                                             # coincident waypoints: a zero-length segment
     _, _, status = v.minsnap(to_dev(dup, v.device))

@@ -563,6 +563,18 @@ __global__ void __launch_bounds__(kLanes) k_minsnap(MinsnapArgs A) {
                 if (failed) break;
             }
             __syncthreads();
+            if (s_flag == 0 && nc > 0) {
+                // the loop above only tests constraints outside its working set; on an infeasible corridor
+                // rounding can hide the vanishing step direction and let it "finish" on an ill-conditioned
+                // working set: every box is verified at the end (as the host solver does)
+                int viol = 0;
+                for (int k = lane; k < nc; k += kLanes) {
+                    double mag;
+                    if (slack_of(k, mag) < -1e-7 * (1.0 + mag)) viol = 1;
+                }
+                if (__any(viol) && lane == 0) s_flag = -2;
+            }
+            __syncthreads();
             if (s_flag != 0) {
                 if (lane == 0) A.out_status[t] = s_flag;
                 return;

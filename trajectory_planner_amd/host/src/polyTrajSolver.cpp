@@ -267,6 +267,14 @@ int solveDenseQP(int n, int m, const std::vector<double>& P, const std::vector<d
     std::vector<double> w;
     const int it = dualActiveSet(nf, Hinv, c, (int)bcon.size(), Acon, bcon, w);
     if (it < 0) return it;
+    // The active-set loop only tests constraints outside its working set.  On an infeasible corridor
+    // rounding can hide the vanishing step direction (z'n ~ 1e-11 n'H^-1 n) and let it "finish" on an
+    // ill-conditioned working set: every box is verified at the end, a violation means infeasible.
+    for (size_t k = 0; k < bcon.size(); ++k) {
+        double sl = -bcon[k];
+        for (int i = 0; i < nf; ++i) sl += Acon[k * nf + i] * w[i];
+        if (sl < -1e-7 * (1.0 + std::fabs(bcon[k]))) return -2;
+    }
     for (int i = 0; i < n; ++i) {
         double s = 0;
         for (int k = 0; k < nf; ++k) s += Zc(i, k) * w[k];
