@@ -27,8 +27,11 @@ int fail(vigo_handle_t h, int code, const char* what, hipError_t e = hipSuccess)
     return code;
 }
 
+// (the launchers report hipGetLastError(): whatever another library of the process — torch, RCCL — left
+// in the thread's last-error slot is discarded first, so it is not mistaken for a failed launch of ours)
 #define VIGO_HIP(h, call)                                                      \
     do {                                                                       \
+        (void)hipGetLastError();                                               \
         hipError_t e_ = (call);                                                \
         if (e_ != hipSuccess) return fail((h), VIGO_ERR_HIP, #call, e_);       \
     } while (0)
