@@ -2,7 +2,7 @@
 shapes (odd extents, z not a multiple of 32), origins, resolutions, control-point counts, sample steps, obstacle
 lists, fit sizes and inflation radii.  Covers vigo_query_points, vigo_guides_unknown, vigo_traj_collision,
 vigo_traj_dynamic_collision, vigo_ctrl_occupancy, vigo_bspline_eval, vigo_bspline_fit (1e-9 vs the oracle's
-pivoted QR), vigo_inflate_grid and vigo_pack_grid.  Not part of the test suite; run on the GPU box:
+pivoted QR), vigo_inflate_grid, vigo_pack_grid, vigo_box_collision_points and vigo_esdf_query.  Not part of the test suite; run on the GPU box:
 python tools/fuzz_map_gates.py [cases] [seed]"""
 import ctypes as C, json, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -16,6 +16,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 31)
 O = ol.oracle()
 bad = 0
+skipped_box = 0
 t0 = time.time()
 
 
@@ -120,8 +121,36 @@ for case in range(cases):
     err = float(np.max(np.abs(got - want)) / max(1.0, float(np.max(np.abs(want)))))
     if not err < 1e-9:
         fail(case, "bspline_fit", K=K, B=Bf, err=err)
+    # box sweep of polyTrajOctomap::checkCollision at single points (float positions, PO.cpp:547-589)
+    box = rng.choice([0.2, 0.4, 0.6, 0.25], size=3)
+    mres = float(rng.choice([0.1, 0.2, res]))
+    bp = origin + rng.uniform(-0.1, 1.1, size=(600, 3)) * ext
+    from trajectory_planner_amd.vigo import VigoError
+    try:
+        gotb = v.box_collision_points(to_dev(bp, v.device), box, mres).cpu().numpy()
+    except VigoError:      # refused: the origin is not on the octomap key lattice (documented in include/vigo.h)
+        gotb = None
+        skipped_box += 1
+    bx = np.ascontiguousarray(box, dtype=np.float64)
+    for i in range(len(bp) if gotb is not None else 0):
+        if O.vgo_box_collision(C.byref(g), float(np.float32(bp[i, 0])), float(np.float32(bp[i, 1])), float(np.float32(bp[i, 2])), ol._d(bx), mres) != gotb[i]:
+            fail(case, "box_collision_points", i=i, box=box.tolist(), map_res=mres, dims=dims)
+            break
+    # trilinear ESDF value + gradient on a random float lattice
+    ed = tuple(int(x) for x in rng.integers(2, 40, size=3))
+    dist = rng.normal(size=ed).astype(np.float32)
+    eo = rng.uniform(-2, 2, size=3)
+    v.set_esdf(to_dev(dist, v.device), eo, res)
+    ep = eo + rng.uniform(-0.2, 1.2, size=(500, 3)) * np.array(ed) * res
+    dq, gq = (t.cpu().numpy() for t in v.esdf_query(to_dev(ep, v.device)))
+    for i in range(len(ep)):
+        dd, gg = C.c_double(), np.zeros(3)
+        O.vgo_esdf_query(ed[0], ed[1], ed[2], ol._d(eo), res, dist.ctypes.data_as(C.POINTER(C.c_float)), ol._d(ep[i]), C.byref(dd), ol._d(gg))
+        if not (dq[i] == dd.value and np.array_equal(gq[i], gg)):
+            fail(case, "esdf_query", i=i, dims=ed)
+            break
     v.close()
     if (case + 1) % 10 == 0:
         print(f"{case + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
-print(json.dumps({"cases": cases, "mismatches": bad, "seconds": time.time() - t0}))
+print(json.dumps({"cases": cases, "mismatches": bad, "box_sweeps_refused_off_lattice": skipped_box, "seconds": time.time() - t0}))
 sys.exit(1 if bad else 0)
