@@ -1,0 +1,145 @@
+"""-m gpu: the C ABI's error behaviour, through raw ctypes (the Python wrapper's own checks bypassed): a NULL
+handle, NULL required pointers, negative or zero counts and out-of-range enumerators must come back as a
+negative vigo_status_t — never a crash, never a launch on garbage — and must leave the handle usable.
+The reference's classes signal errors by `false` / early return (bsplineTraj.cpp:333-343, polyTrajOctomap.cpp:
+226-238); the facades translate these codes into that behaviour."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from trajectory_planner_amd import _lib
+
+pytestmark = pytest.mark.gpu
+NULL = C.c_void_p(0)
+
+
+@pytest.fixture(scope="module")
+def raw():
+    L = _lib.load()
+    h = C.c_void_p()
+    assert L.vigo_create(C.byref(h), 0) == 0
+    yield L, h
+    assert L.vigo_destroy(h) == 0
+
+
+def dptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def test_null_handle_is_refused_everywhere(raw):
+    L, _ = raw
+    d = torch.zeros(64, dtype=torch.float64, device="cuda")
+    o = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    three = (C.c_double * 3)(0, 0, 0)
+    calls = [
+        lambda: L.vigo_set_stream(NULL, NULL),
+        lambda: L.vigo_set_params(NULL, None),
+        lambda: L.vigo_get_params(NULL, None),
+        lambda: L.vigo_set_precision(NULL, 0),
+        lambda: L.vigo_set_grid(NULL, 4, 4, 4, three, 0.1, dptr(o)),
+        lambda: L.vigo_inflate_grid(NULL, 4, 4, 4, dptr(o), 1, 1, 1),
+        lambda: L.vigo_pack_grid(NULL, 4, 4, 4, dptr(o), dptr(d)),
+        lambda: L.vigo_set_metric_bounds(NULL, three, three),
+        lambda: L.vigo_query_points(NULL, 0, 1, dptr(d), dptr(o)),
+        lambda: L.vigo_guides_unknown(NULL, 1, dptr(d), dptr(o)),
+        lambda: L.vigo_bspline_fit(NULL, 1, 8, 0.1, dptr(d), NULL, dptr(d)),
+        lambda: L.vigo_ctrl_occupancy(NULL, 1, 8, dptr(d), dptr(o), dptr(o)),
+        lambda: L.vigo_box_collision_points(NULL, 1, dptr(d), three, 0.1, dptr(o)),
+        lambda: L.vigo_esdf_query(NULL, 1, dptr(d), dptr(d), dptr(d)),
+        lambda: L.vigo_destroy(NULL),
+    ]
+    for i, f in enumerate(calls):
+        assert f() < 0, i
+    L.vigo_last_error(NULL)                            # a static message or NULL, not a crash
+
+
+def test_bad_arguments_return_codes_and_keep_the_handle_usable(raw):
+    L, h = raw
+    dev = torch.device("cuda", 0)
+    vox = torch.zeros(8, 8, 40, dtype=torch.uint8, device=dev)
+    origin = (C.c_double * 3)(0, 0, 0)
+    d = torch.zeros(4096, dtype=torch.float64, device=dev)
+    o = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    i32 = torch.zeros(4096, dtype=torch.int32, device=dev)
+    # map entry points: before a grid, with bad dims, with NULL data
+    assert L.vigo_set_grid(h, 0, 8, 8, origin, 0.1, dptr(vox)) < 0
+    assert L.vigo_set_grid(h, 8, 8, -1, origin, 0.1, dptr(vox)) < 0
+    assert L.vigo_set_grid(h, 8, 8, 40, origin, 0.0, dptr(vox)) < 0
+    assert L.vigo_set_grid(h, 8, 8, 40, origin, float("nan"), dptr(vox)) < 0
+    assert L.vigo_set_grid(h, 8, 8, 40, origin, 0.1, NULL) < 0
+    assert L.vigo_set_grid(h, 8, 8, 40, None, 0.1, dptr(vox)) < 0
+    assert L.vigo_inflate_grid(h, 8, 8, 40, NULL, 1, 1, 1) < 0
+    assert L.vigo_inflate_grid(h, 8, 8, 40, dptr(vox), -1, 0, 0) < 0
+    assert L.vigo_pack_grid(h, 8, 8, 40, NULL, dptr(d)) < 0
+    assert L.vigo_pack_grid(h, 8, 8, 40, dptr(vox), NULL) < 0
+    assert L.vigo_set_grid(h, 8, 8, 40, origin, 0.1, dptr(vox)) == 0
+    assert L.vigo_query_points(h, 0, 4, NULL, dptr(o)) < 0
+    assert L.vigo_query_points(h, 0, 4, dptr(d), NULL) < 0
+    assert L.vigo_query_points(h, 7, 4, dptr(d), dptr(o)) < 0          # no such plane
+    assert L.vigo_query_points(h, 0, -4, dptr(d), dptr(o)) < 0
+    assert L.vigo_query_points(h, 0, 0, NULL, NULL) == 0                 # empty is fine
+    assert L.vigo_guides_unknown(h, 3, NULL, dptr(o)) < 0
+    # solver entry points
+    for B, N, ctrl in ((1, 32, NULL), (-1, 32, dptr(d)), (1, 6, dptr(d)), (1, 100000, dptr(d))):
+        assert L.vigo_optimize(h, B, N, ctrl, NULL, NULL, NULL, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL) < 0, (B, N)
+        assert L.vigo_cost_grad(h, B, N, ctrl, NULL, NULL, NULL, NULL, NULL, 0, NULL, dptr(d), dptr(d), NULL) < 0, (B, N)
+    # offsets without the data they index (a NULL dereference on the device if it were launched)
+    assert L.vigo_optimize(h, 1, 32, dptr(d), dptr(i32), NULL, NULL, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL) < 0
+    assert L.vigo_optimize(h, 1, 32, dptr(d), NULL, NULL, NULL, dptr(i32), NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL) < 0
+    assert L.vigo_optimize(h, 1, 32, dptr(d), NULL, NULL, NULL, NULL, NULL, 3, NULL, NULL, NULL, NULL, NULL, NULL) < 0
+    assert L.vigo_optimize(h, 1, 32, dptr(d), NULL, NULL, NULL, NULL, dptr(d), -3, NULL, NULL, NULL, NULL, NULL, NULL) < 0
+    assert L.vigo_cost_grad(h, 1, 32, dptr(d), dptr(i32), NULL, NULL, NULL, NULL, 0, NULL, dptr(d), dptr(d), NULL) < 0
+    assert L.vigo_traj_dynamic_collision(h, 1, 8, dptr(d), 0.05, dptr(i32), NULL, 0, dptr(o)) < 0
+    assert L.vigo_traj_dynamic_collision(h, 1, 8, dptr(d), 0.05, NULL, NULL, 2, dptr(o)) < 0
+    assert L.vigo_optimize(h, 0, 32, NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL) == 0   # empty batch
+    assert L.vigo_set_precision(h, 17) < 0
+    assert L.vigo_set_params(h, None) < 0
+    # spline / gates
+    assert L.vigo_bspline_fit(h, 1, 1, 0.1, dptr(d), NULL, dptr(d)) < 0                 # fewer than 2 waypoints
+    assert L.vigo_bspline_fit(h, 1, 8, 0.0, dptr(d), NULL, dptr(d)) < 0
+    assert L.vigo_bspline_fit(h, 1, 8, 0.1, NULL, NULL, dptr(d)) < 0
+    assert L.vigo_bspline_fit(h, 1, 8, 0.1, dptr(d), NULL, NULL) < 0
+    assert L.vigo_bspline_eval(h, 1, 2, dptr(d), 0, 4, dptr(d), dptr(d)) < 0            # N < degree + 1
+    assert L.vigo_bspline_eval(h, 1, 8, dptr(d), 5, 4, dptr(d), dptr(d)) < 0            # no such derivative
+    assert L.vigo_bspline_eval(h, 1, 8, NULL, 0, 4, dptr(d), dptr(d)) < 0
+    assert L.vigo_traj_collision(h, 1, 8, dptr(d), 0.0, dptr(o), NULL) < 0               # dt must be positive
+    assert L.vigo_traj_collision(h, 1, 8, dptr(d), -1.0, dptr(o), NULL) < 0
+    assert L.vigo_traj_collision(h, 1, 8, dptr(d), float("nan"), dptr(o), NULL) < 0
+    assert L.vigo_traj_collision(h, 1, 8, NULL, 0.05, dptr(o), NULL) < 0
+    assert L.vigo_traj_collision(h, 1, 8, dptr(d), 0.05, NULL, NULL) < 0
+    assert L.vigo_traj_dynamic_collision(h, 1, 8, dptr(d), 0.05, NULL, dptr(d), -1, dptr(o)) < 0
+    assert L.vigo_ctrl_occupancy(h, 1, 8, NULL, dptr(o), dptr(o)) < 0
+    # min-snap / corridor
+    assert L.vigo_minsnap(h, 1, 1, 7, 4, 4, 1.0, 8.0, dptr(d), NULL, NULL, dptr(d), dptr(d), dptr(i32)) < 0     # one waypoint
+    assert L.vigo_minsnap(h, 1, 4, 7, 4, 4, 0.0, 8.0, dptr(d), NULL, NULL, dptr(d), dptr(d), dptr(i32)) < 0     # zero speed
+    assert L.vigo_minsnap(h, 1, 4, 7, 4, 4, 1.0, 8.0, NULL, NULL, NULL, dptr(d), dptr(d), dptr(i32)) < 0
+    assert L.vigo_minsnap(h, 1, 4, 7, 4, 4, 1.0, 8.0, dptr(d), NULL, NULL, NULL, dptr(d), dptr(i32)) < 0
+    box = (C.c_double * 3)(0.4, 0.4, 0.2)
+    assert L.vigo_corridor_check(h, 1, 7, NULL, dptr(i32), dptr(d), box, 0.1, dptr(o), NULL, NULL) < 0
+    assert L.vigo_corridor_check(h, 1, 99, dptr(d), dptr(i32), dptr(d), box, 0.1, dptr(o), NULL, NULL) < 0
+    assert L.vigo_corridor_check(h, 1, 7, dptr(d), dptr(i32), dptr(d), box, 0.0, dptr(o), NULL, NULL) < 0
+    assert L.vigo_corridor_check(h, 1, 7, dptr(d), dptr(i32), dptr(d), None, 0.1, dptr(o), NULL, NULL) < 0
+    assert L.vigo_box_collision_points(h, 4, NULL, box, 0.1, dptr(o)) < 0
+    assert L.vigo_box_collision_points(h, 4, dptr(d), box, -0.1, dptr(o)) < 0
+    # ESDF
+    assert L.vigo_esdf_query(h, 4, dptr(d), dptr(d), dptr(d)) < 0                        # before vigo_set_esdf
+    f32 = torch.zeros(64, dtype=torch.float32, device=dev)
+    assert L.vigo_set_esdf(h, 1, 4, 4, origin, 0.1, dptr(f32)) < 0                       # a trilinear cell needs 2 samples per axis
+    assert L.vigo_set_esdf(h, 4, 4, 4, origin, 0.1, NULL) < 0
+    assert L.vigo_set_esdf(h, 4, 4, 4, origin, 0.1, dptr(f32)) == 0
+    assert L.vigo_esdf_query(h, 4, NULL, dptr(d), dptr(d)) < 0
+    torch.cuda.synchronize()
+    # every refusal left a message, and the handle still works
+    assert len(L.vigo_last_error(h)) > 0
+    pts = torch.zeros(4, 3, dtype=torch.float64, device=dev)
+    out = torch.full((4,), 9, dtype=torch.uint8, device=dev)
+    assert L.vigo_query_points(h, 0, 4, dptr(pts), dptr(out)) == 0
+    assert out.cpu().tolist() == [0, 0, 0, 0]
+    ctrl = torch.zeros(2, 32, 3, dtype=torch.float64, device=dev)
+    ctrl[:, :, 0] = torch.arange(32, dtype=torch.float64, device=dev) * 0.01
+    st = torch.full((2,), 77, dtype=torch.int32, device=dev)
+    assert L.vigo_optimize(h, 2, 32, dptr(ctrl), NULL, NULL, NULL, NULL, NULL, 0, NULL, NULL, dptr(st), NULL, NULL, NULL) == 0
+    torch.cuda.synchronize()
+    assert (st.cpu().numpy() != 77).all() and bool(torch.isfinite(ctrl).all())

@@ -54,6 +54,16 @@ int check_solve_args(vigo_handle_t h, int B, int N, const void* ctrl) {
     return VIGO_OK;
 }
 
+// The list arguments shared by the solve entry points and the dynamic gate: offsets without the data they
+// index would be a NULL dereference on the device (the offsets themselves live there and cannot be checked).
+int check_list_args(vigo_handle_t h, const void* guide_off, const void* guide_pv, const void* obs_off, const void* obs, int n_obs_shared) {
+    if (n_obs_shared < 0) return fail(h, VIGO_ERR_INVALID_ARG, "n_obs_shared < 0");
+    if (guide_off && !guide_pv) return fail(h, VIGO_ERR_INVALID_ARG, "guide_off without guide_pv");
+    if (obs_off && !obs) return fail(h, VIGO_ERR_INVALID_ARG, "obs_off without obs");
+    if (!obs_off && n_obs_shared > 0 && !obs) return fail(h, VIGO_ERR_INVALID_ARG, "n_obs_shared > 0 without obs");
+    return VIGO_OK;
+}
+
 // Sample times of `for (t = 0; t <= tmax; t += dt)` (BT.h:313, :347): t_k is the k-fold floating point
 // accumulation, reproduced exactly by vigo::accumulated_time (closed form per binade).  The sample count T is
 // found on the host by bisection over that closed form (monotone in k), the table is filled by a device kernel
@@ -331,7 +341,8 @@ int vigo_cost_grad(vigo_handle_t h, int B, int N, const double* ctrl, const int3
                    double* out_grad, double* out_terms) {
     int rc = check_solve_args(h, B, N, ctrl);
     if (rc) return rc;
-    if (n_obs_shared < 0) return fail(h, VIGO_ERR_INVALID_ARG, "n_obs_shared < 0");
+    rc = check_list_args(h, guide_off, guide_pv, obs_off, obs, n_obs_shared);
+    if (rc) return rc;
     SolveArgs a{};
     a.B = B; a.N = N;
     a.ctrl = const_cast<double*>(ctrl);
@@ -349,7 +360,8 @@ int vigo_optimize(vigo_handle_t h, int B, int N, double* ctrl, const int32_t* gu
                   int32_t* out_status, double* out_fx, int32_t* out_iters, int32_t* out_evals) {
     int rc = check_solve_args(h, B, N, ctrl);
     if (rc) return rc;
-    if (n_obs_shared < 0) return fail(h, VIGO_ERR_INVALID_ARG, "n_obs_shared < 0");
+    rc = check_list_args(h, guide_off, guide_pv, obs_off, obs, n_obs_shared);
+    if (rc) return rc;
     SolveArgs a{};
     a.B = B; a.N = N;
     a.ctrl = ctrl;
@@ -425,10 +437,12 @@ int vigo_traj_dynamic_collision(vigo_handle_t h, int B, int N, const double* ctr
     if (!h) return VIGO_ERR_INVALID_ARG;
     if (B < 0 || (B > 0 && (!ctrl || !out_flag)) || n_obs_shared < 0) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_traj_dynamic_collision: bad argument");
     if (N < 4 || N > VIGO_MAX_CTRL_POINTS) return fail(h, VIGO_ERR_UNSUPPORTED_N, "N outside [4, VIGO_MAX_CTRL_POINTS]");
+    int rc = check_list_args(h, nullptr, nullptr, obs_off, obs, n_obs_shared);
+    if (rc) return rc;
     int T = 0;
     const double* times = nullptr;
     double duration = (N - 3) * h->params.ts_ctrl;
-    int rc = upload_sample_times(h, duration, dt, &T, &times);
+    rc = upload_sample_times(h, duration, dt, &T, &times);
     if (rc) return rc;
     VIGO_HIP(h, (hipError_t)vigo::launch_traj_dynamic_collision(h->stream, B, N, ctrl, h->params.ts_ctrl, T, times, obs_off, obs, n_obs_shared, out_flag));
     return VIGO_OK;
