@@ -31,6 +31,8 @@
  *   obs_off     int32 [B + 1]        CSR offsets of dynamic obstacles per trajectory, or NULL
  *                                       with n_obs_shared obstacles shared by the whole batch
  *   obs         double[O][9]         (pos.xyz vel.xyz size.xyz)  (BT.h:26-28)
+ *                                       guide_pv == NULL / obs == NULL mean "no guides" / "no
+ *                                       obstacles" whatever the offsets say (they are not read)
  *   weights     double[B][4]         (distance, smoothness, feasibility, dynamic) per
  *                                       trajectory; NULL => the handle's params.  The rebound
  *                                       loop doubles them per trajectory (BT.cpp:667,672,678).

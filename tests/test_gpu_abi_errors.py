@@ -85,14 +85,23 @@ def test_bad_arguments_return_codes_and_keep_the_handle_usable(raw):
     for B, N, ctrl in ((1, 32, NULL), (-1, 32, dptr(d)), (1, 6, dptr(d)), (1, 100000, dptr(d))):
         assert L.vigo_optimize(h, B, N, ctrl, NULL, NULL, NULL, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL) < 0, (B, N)
         assert L.vigo_cost_grad(h, B, N, ctrl, NULL, NULL, NULL, NULL, NULL, 0, NULL, dptr(d), dptr(d), NULL) < 0, (B, N)
-    # offsets without the data they index (a NULL dereference on the device if it were launched)
-    assert L.vigo_optimize(h, 1, 32, dptr(d), dptr(i32), NULL, NULL, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL) < 0
-    assert L.vigo_optimize(h, 1, 32, dptr(d), NULL, NULL, NULL, dptr(i32), NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL) < 0
-    assert L.vigo_optimize(h, 1, 32, dptr(d), NULL, NULL, NULL, NULL, NULL, 3, NULL, NULL, NULL, NULL, NULL, NULL) < 0
+    # offsets (or a shared count) without the list they index mean "none": the kernels must not touch the
+    # missing list.  The offsets here claim 5 pairs / obstacles per entry, so a dereference would fault.
+    i32[:] = torch.arange(4096, dtype=torch.int32, device=dev) * 5
+    ok_ctrl = torch.zeros(1, 32, 3, dtype=torch.float64, device=dev)
+    ok_ctrl[0, :, 0] = torch.arange(32, dtype=torch.float64, device=dev) * 0.2
+    base = ok_ctrl.clone()
+    assert L.vigo_optimize(h, 1, 32, dptr(base), NULL, NULL, NULL, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL) == 0
+    for goff, ooff, ns in ((dptr(i32), NULL, 0), (NULL, dptr(i32), 0), (NULL, NULL, 3), (dptr(i32), dptr(i32), 7)):
+        c = ok_ctrl.clone()
+        assert L.vigo_optimize(h, 1, 32, dptr(c), goff, NULL, NULL, ooff, NULL, ns, NULL, NULL, NULL, NULL, NULL, NULL) == 0
+        assert torch.equal(c, base)                      # same result as with no lists at all
+        assert L.vigo_cost_grad(h, 1, 32, dptr(c), goff, NULL, NULL, ooff, NULL, ns, NULL, dptr(d), dptr(d), NULL) == 0
     assert L.vigo_optimize(h, 1, 32, dptr(d), NULL, NULL, NULL, NULL, dptr(d), -3, NULL, NULL, NULL, NULL, NULL, NULL) < 0
-    assert L.vigo_cost_grad(h, 1, 32, dptr(d), dptr(i32), NULL, NULL, NULL, NULL, 0, NULL, dptr(d), dptr(d), NULL) < 0
-    assert L.vigo_traj_dynamic_collision(h, 1, 8, dptr(d), 0.05, dptr(i32), NULL, 0, dptr(o)) < 0
-    assert L.vigo_traj_dynamic_collision(h, 1, 8, dptr(d), 0.05, NULL, NULL, 2, dptr(o)) < 0
+    assert L.vigo_traj_dynamic_collision(h, 1, 8, dptr(d), 0.05, dptr(i32), NULL, 0, dptr(o)) == 0
+    assert L.vigo_traj_dynamic_collision(h, 1, 8, dptr(d), 0.05, NULL, NULL, 2, dptr(o)) == 0
+    torch.cuda.synchronize()
+    i32.zero_()
     assert L.vigo_optimize(h, 0, 32, NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL) == 0   # empty batch
     assert L.vigo_set_precision(h, 17) < 0
     assert L.vigo_set_params(h, None) < 0

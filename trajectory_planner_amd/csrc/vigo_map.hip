@@ -187,8 +187,8 @@ __global__ void __launch_bounds__(64) k_traj_dynamic_collision(int B, int N, con
     const int b = blockIdx.x;
     if (b >= B) return;
     const double* c = ctrl + (size_t)b * N * 3;
-    const int o0 = obs_off ? obs_off[b] : 0;
-    const int o1 = obs_off ? obs_off[b + 1] : (obs ? n_obs_shared : 0);
+    const int o0 = (obs && obs_off) ? obs_off[b] : 0;
+    const int o1 = !obs ? 0 : (obs_off ? obs_off[b + 1] : n_obs_shared);
     int hit = 0;
     for (int k = threadIdx.x; k < T && !hit; k += 64) {
         double p[3];

@@ -553,7 +553,7 @@ __device__ __forceinline__ void load_problem(const SolveArgs& A, const DevConst&
         Q.has_pt[q] = p < N;
         Q.interior[q] = (p >= 3) && (p <= N - 4);
         Q.g_begin[q] = Q.g_end[q] = 0;
-        if (Q.interior[q] && A.guide_off) {
+        if (Q.interior[q] && A.guide_off && A.guide_pv) {   // offsets without pairs: no guides
             Q.g_begin[q] = A.guide_off[(size_t)b * N + p];
             Q.g_end[q] = A.guide_off[(size_t)b * N + p + 1];
         }
@@ -573,7 +573,9 @@ __device__ __forceinline__ void load_problem(const SolveArgs& A, const DevConst&
     Q.obs = A.obs;
     Q.obs_tab = Q.obs_size = nullptr;
     Q.o_tab = Q.o_steps = 0;
-    if (A.obs_off) {
+    if (!A.obs) {                    // offsets (or a shared count) without the list: no obstacles
+        Q.o_begin = Q.o_end = 0;
+    } else if (A.obs_off) {
         Q.o_begin = A.obs_off[b];
         Q.o_end = A.obs_off[b + 1];
     } else {

@@ -61,6 +61,8 @@ public:
      * un-normalised local time, (deg+1) per segment; knots must be getTimeKnot()'s */
     void installSolution(const std::vector<double>& x, const std::vector<double>& y, const std::vector<double>& z);
     bool solve();   // the reference's solve() is void and silently keeps a stale solution on failure
+    /* all three axes hold a polynomial (false until the first success: an infeasible first corridor leaves nothing to sample) */
+    bool hasSolution() const { return !xSol_.empty() && !ySol_.empty() && !zSol_.empty(); }
     pose getPose(double t);
     void getTrajectory(std::vector<pose>& trajectory, double delT);
     std::vector<double>& getTimeKnot();

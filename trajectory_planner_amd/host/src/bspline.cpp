@@ -23,6 +23,9 @@ void bspline::initKnots() {
 
 // de Boor; at exact knots the lower span is used (bspline.cpp:37-42)
 Eigen::Vector3d bspline::at(double t) {
+    // an empty spline (a planner whose makePlan() never succeeded) evaluates to the origin instead of
+    // reading past its control points; the reference has undefined behaviour there
+    if (controlPoints_.cols() < degree_ + 1 || degree_ < 0 || degree_ > 7) return Eigen::Vector3d(0.0, 0.0, 0.0);
     const double tb = std::min(std::max(0.0, t), duration_);
     int k = degree_;
     while (!(knot(k + 1) >= tb)) ++k;
@@ -40,6 +43,7 @@ Eigen::Vector3d bspline::at(double t) {
 double bspline::getDuration() { return duration_; }
 
 bspline bspline::getDerivative() {
+    if (controlPoints_.cols() < 2 || degree_ < 1) return bspline();
     Eigen::MatrixXd ctp(controlPoints_.rows(), controlPoints_.cols() - 1);
     for (int i = 0; i < ctp.cols(); ++i) {
         const double den = knot(i + degree_ + 1) - knot(i + 1);

@@ -232,6 +232,9 @@ void polyTrajOctomap::makePlanCorridorConstraint(std::vector<pose>& trajectory, 
         if (nowSec() - t0 >= timeout_) { cout << "[Trajectory Planner INFO]: Timeout." << endl; break; }
         trajSolver_->setCorridorConstraint(corridorSizeVec, corridorRes_);
         trajSolver_->solve();
+        // an infeasible corridor keeps the previous polynomial, like the reference; with none to keep (the very
+        // first corridor was infeasible, and shrinking it cannot help) there is nothing to sample: not found
+        if (!trajSolver_->hasSolution()) break;
         trajSolver_->getTrajectory(trajectory, delT);
         std::set<int> collisionSeg;
         valid = !this->checkCollisionTraj(trajectory, delT, collisionSeg);
@@ -257,6 +260,7 @@ void polyTrajOctomap::makePlanAddingWaypoint(std::vector<pose>& trajectory, doub
     while (!valid) {
         if (nowSec() - t0 >= timeout_) { cout << "[Trajectory Planner INFO]: Timeout." << endl; break; }
         trajSolver_->solve();
+        if (!trajSolver_->hasSolution()) break;   // degenerate path (e.g. coincident waypoints): nothing to sample
         trajSolver_->getTrajectory(trajectory, delT);
         std::set<int> collisionSeg;
         valid = !this->checkCollisionTraj(trajectory, delT, collisionSeg);
@@ -366,6 +370,12 @@ std::vector<bool> polyTrajOctomap::makePlanBatch(const std::vector<polyTrajOctom
                     }
                 p->trajSolver_->installSolution(xs, ys, zs);
             }
+            if (!p->trajSolver_->hasSolution()) {      // first corridor infeasible: not found (see makePlanCorridorConstraint)
+                trajectories[grp[act[a]]].clear();
+                st[act[a]].active = false;
+                first[a + 1] = pts.size() / 3;
+                continue;
+            }
             p->trajSolver_->getTrajectory(trajectories[grp[act[a]]], p->delT_);
             for (const pose& q : trajectories[grp[act[a]]]) { pts.push_back(q.x); pts.push_back(q.y); pts.push_back(q.z); }
             first[a + 1] = pts.size() / 3;
@@ -388,6 +398,7 @@ std::vector<bool> polyTrajOctomap::makePlanBatch(const std::vector<polyTrajOctom
         for (int a = 0; a < T; ++a) {
             const size_t g = act[a];
             polyTrajOctomap* p = ps[grp[g]];
+            if (!st[g].active) continue;               // retired above without a polynomial
             const std::vector<double>& knots = p->trajSolver_->getTimeKnot();
             std::set<int> collisionSeg;   // PO.cpp:634-656
             double t = 0;

@@ -475,7 +475,7 @@ void polyTrajSolver::installSolution(const std::vector<double>& x, const std::ve
 // PS.cpp:1026-1056
 pose polyTrajSolver::getPose(double t) {
     pose p;
-    if (xSol_.empty()) return p;
+    if (!hasSolution()) return p;
     for (size_t i = 0; i + 1 < desiredTime_.size(); ++i) {
         const double startTime = desiredTime_[i], endTime = desiredTime_[i + 1];
         if (t >= startTime && t <= endTime) {

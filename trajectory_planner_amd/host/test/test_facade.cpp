@@ -159,7 +159,7 @@ int main() {
             single.updatePath(paths[5], cond);
             Eigen::MatrixXd a = single.getControlPoints(), d = ps[5]->getControlPoints();
             double worst = 0;
-            for (int c = 0; c < a.cols(); ++c) for (int r = 0; r < 3; ++r) worst = std::fmax(worst, std::fabs(a(r, c) - d(r, c)));
+            for (int c = 0; c < a.cols() && c < d.cols(); ++c) for (int r = 0; r < 3; ++r) worst = std::fmax(worst, std::fabs(a(r, c) - d(r, c)));
             CHECK(a.cols() == d.cols() && worst < 1e-10, "device batch fit == host single-path fit (1e-10)");
         }
         std::vector<bool> res = bsplineTraj::makePlanBatch(ps);
@@ -266,6 +266,134 @@ int main() {
         std::printf("INFO poly batch: %d of %zu valid; solo-vs-batch max diff %.3e\n", valid, ps.size(), worst);
         CHECK(valid >= 20 && agree == (int)ps.size(), "polyTrajOctomap::makePlanBatch: valid plans are collision free");
         CHECK(t2.size() == trajs[3].size() && worst < 1e-6 && solo->isValid() == res[3], "batch plan == single makePlan (device QP == host QP)");
+    }
+
+    // ---- randomised stress (VIGO_FACADE_FUZZ=<rounds>, default 3): random box worlds, random straight paths with
+    //      free end points, dynamic obstacles on a third of the planners.  No success rate is demanded (a random
+    //      world may wall a path in); what is demanded: no crash, and every plan reported successful is collision
+    //      free by the host-side gate (isCurrTrajValid: host spline + host copy of the map) ----
+    {
+        const char* fz = std::getenv("VIGO_FACADE_FUZZ");
+        const int rounds = fz ? std::atoi(fz) : 3;
+        unsigned long long st = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0; };
+        int planned = 0, total = 0, dirty = 0, clipped = 0, polyValid = 0, polyTotal = 0, polyDirty = 0;
+        for (int round = 0; round < rounds; ++round) {
+            auto m = std::make_shared<mapManager::occMap>(128, 128, 40, Eigen::Vector3d(-6.4, -6.4, -0.5), 0.1);
+            const int nb = 3 + (int)(rnd() * 10);
+            for (int b = 0; b < nb; ++b) {
+                const double cx = -4.5 + 9.0 * rnd(), cy = -4.5 + 9.0 * rnd(), hx = 0.15 + 0.6 * rnd(), hy = 0.15 + 0.6 * rnd(), top = 0.5 + 3.0 * rnd();
+                for (int ix = 0; ix < 128; ++ix) for (int iy = 0; iy < 128; ++iy) for (int iz = 0; iz < 40; ++iz) {
+                    const double x = -6.4 + (ix + 0.5) * 0.1, y = -6.4 + (iy + 0.5) * 0.1, z = -0.5 + (iz + 0.5) * 0.1;
+                    if (std::fabs(x - cx) <= hx && std::fabs(y - cy) <= hy && z <= top) m->at(ix, iy, iz) |= 4;
+                    if (std::fabs(x - cx) <= hx + 0.4 && std::fabs(y - cy) <= hy + 0.4 && z <= top + 0.15) m->at(ix, iy, iz) |= 1;
+                }
+            }
+            auto freePoint = [&](double& x, double& y) {
+                for (int tries = 0; tries < 200; ++tries) {
+                    x = -5.0 + 10.0 * rnd(); y = -5.0 + 10.0 * rnd();
+                    if (!m->isInflatedOccupied(Eigen::Vector3d(x, y, 1.0))) return true;
+                }
+                return false;
+            };
+            const int NPR = 40 + (int)(rnd() * 60);
+            std::vector<std::unique_ptr<bsplineTraj>> owners;
+            std::vector<bsplineTraj*> ps;
+            std::vector<nav_msgs::Path> paths;
+            std::vector<double> vels, readyVel;
+            for (int i = 0; i < NPR; ++i) {
+                double x0, y0, x1, y1;
+                if (!freePoint(x0, y0) || !freePoint(x1, y1) || std::hypot(x1 - x0, y1 - y0) < 2.0) continue;
+                owners.emplace_back(new bsplineTraj(makeParams()));
+                owners.back()->setMap(m);
+                vels.push_back(1.0 + 2.0 * rnd());
+                owners.back()->updateMaxVel(vels.back());
+                owners.back()->updateMaxAcc(2.0 + 2.0 * rnd());
+                if (i % 3 == 0) {
+                    const double f = rnd();
+                    std::vector<Eigen::Vector3d> op{Eigen::Vector3d(x0 + (x1 - x0) * f + 0.8 * (rnd() - 0.5), y0 + (y1 - y0) * f + 0.8 * (rnd() - 0.5), 1.0)};
+                    std::vector<Eigen::Vector3d> ov{Eigen::Vector3d(rnd() - 0.5, rnd() - 0.5, 0.0)};
+                    std::vector<Eigen::Vector3d> os{Eigen::Vector3d(0.4 + 0.4 * rnd(), 0.4 + 0.4 * rnd(), 1.5)};
+                    owners.back()->updateDynamicObstacles(op, ov, os);
+                }
+                ps.push_back(owners.back().get());
+                paths.push_back(straight(x0, y0, x1, y1, 1.0, 0.25));
+            }
+            std::vector<bool> up = bsplineTraj::updatePathBatch(ps, paths, std::vector<std::vector<Eigen::Vector3d>>(ps.size(), cond));
+            std::vector<bsplineTraj*> ready;
+            for (size_t i = 0; i < ps.size(); ++i) if (up[i]) { ready.push_back(ps[i]); readyVel.push_back(vels[i]); }
+            std::vector<bool> res = bsplineTraj::makePlanBatch(ready);
+            for (size_t i = 0; i < ready.size(); ++i) {
+                ++total;
+                if (!res[i]) continue;
+                ++planned;
+                bool hit = false, finite = true;
+                const double dur = ready[i]->getDuration();
+                for (double t = 0.0; t <= dur; t += 0.01) {
+                    const geometry_msgs::PoseStamped ps1 = ready[i]->getPose(t);
+                    const Eigen::Vector3d q(ps1.pose.position.x, ps1.pose.position.y, ps1.pose.position.z);
+                    finite = finite && std::isfinite(q(0)) && std::isfinite(q(1)) && std::isfinite(q(2));
+                    hit = hit || m->isInflatedOccupied(q);
+                }
+                // the reference's own criterion (host evalTraj at the gate's sample step + the host map) must hold;
+                // the 10 ms sampling is finer than that gate (res / maxVel / 2 in spline time) and may see a clipped
+                // voxel corner between two gate samples — the reference's gate has the same blind spot: reported only
+                bool gateHit = false;                      // BT.h:307-325 on the host: host spline, host map, same sample step
+                {
+                    trajPlanner::bspline sp(3, ready[i]->getControlPoints(), ready[i]->getControlPointTs());
+                    const double dtg = m->getRes() / readyVel[i] / 2.0;
+                    for (double t = 0.0; t <= sp.getDuration(); t += dtg) gateHit = gateHit || m->isInflatedOccupied(sp.at(t));
+                }
+                if (gateHit || !ready[i]->isCurrTrajValid() || !finite || !(dur > 0)) ++dirty;
+                if (hit) ++clipped;
+            }
+            // min-snap planners through the same world: 3-6 free waypoints each, corridor mode
+            std::vector<std::unique_ptr<trajPlanner::polyTrajOctomap>> pown;
+            std::vector<trajPlanner::polyTrajOctomap*> pp;
+            std::vector<std::vector<trajPlanner::pose>> pwps;
+            for (int i = 0; i < 24; ++i) {
+                ros::NodeHandle nh;
+                nh.setParam("collision_box", std::vector<double>{0.4, 0.4, 0.2});
+                nh.setParam("map_resolution", 0.2);
+                nh.setParam("sample_delta_time", 0.1);
+                nh.setParam("mode", (double)(i % 2));
+                nh.setParam("initial_radius", 0.5);
+                nh.setParam("shrinking_factor", 0.8);
+                nh.setParam("corridor_res", 8.0);
+                nh.setParam("maximum_iteration_num", 20.0);
+                nh.setParam("traj_timeout", 0.5);
+                std::vector<trajPlanner::pose> wp;
+                const int nw = 3 + (int)(rnd() * 4);
+                double x, y;
+                bool okp = true;
+                for (int k = 0; k < nw && okp; ++k) { okp = freePoint(x, y); wp.push_back(trajPlanner::pose(x, y, 1.0)); }
+                if (!okp) continue;
+                pown.emplace_back(new trajPlanner::polyTrajOctomap(nh));
+                pown.back()->setMap(m);
+                pown.back()->updatePath(wp);
+                pp.push_back(pown.back().get());
+                pwps.push_back(wp);
+            }
+            std::vector<std::vector<trajPlanner::pose>> trajs;
+            std::vector<bool> pres = trajPlanner::polyTrajOctomap::makePlanBatch(pp, trajs);
+            for (size_t i = 0; i < pp.size(); ++i) {
+                ++polyTotal;
+                if (!pres[i]) continue;
+                ++polyValid;
+                // a valid plan starts at the first waypoint and ends at the last (never a default-constructed pose)
+                bool hit = trajs[i].size() < 2 || std::fabs(trajs[i].front().x - pwps[i].front().x) + std::fabs(trajs[i].front().y - pwps[i].front().y) > 1e-6 ||
+                           std::fabs(trajs[i].back().x - pwps[i].back().x) + std::fabs(trajs[i].back().y - pwps[i].back().y) > 1e-6;
+                for (const auto& q : trajs[i]) {
+                    if (!(std::isfinite(q.x) && std::isfinite(q.y) && std::isfinite(q.z))) hit = true;
+                    else if (m->byteAt(Eigen::Vector3d(q.x, q.y, q.z)) & 4u) hit = true;      // the pose itself inside an occupied voxel
+                }
+                if (hit) ++polyDirty;
+            }
+        }
+        std::printf("INFO stress: %d rounds; bsplineTraj %d of %d planned, %d failed the host gate, %d clip a voxel between gate samples; polyTrajOctomap %d of %d valid, %d dirty\n",
+                    rounds, planned, total, dirty, clipped, polyValid, polyTotal, polyDirty);
+        CHECK(dirty == 0 && planned > 0, "stress: every bsplineTraj success is collision free on the host copy of the map");
+        CHECK(polyDirty == 0, "stress: every valid polyTrajOctomap plan keeps its poses out of occupied voxels");
     }
 
     std::printf("%s (%d failures)\n", fails ? "FAILED" : "PASSED", fails);
