@@ -32,11 +32,12 @@ struct Walker {
             kmax[a] = std::max(kmax[a], lo[a] + size - 1);
         }
         if (!map) return;
-        for (int x = x0; x < x0 + size; ++x)
-            for (int y = y0; y < y0 + size; ++y)
-                for (int z = z0; z < z0 + size; ++z) {
-                    const int ix = x - o[0], iy = y - o[1], iz = z - o[2];
-                    if (ix < 0 || iy < 0 || iz < 0 || ix >= map->nx() || iy >= map->ny() || iz >= map->nz()) continue;
+        // (the leaf clipped to the map first: a pruned leaf high in the tree is up to 32768 keys wide)
+        const int b0[3] = {std::max(x0 - o[0], 0), std::max(y0 - o[1], 0), std::max(z0 - o[2], 0)};
+        const int b1[3] = {std::min(x0 + size - o[0], map->nx()), std::min(y0 + size - o[1], map->ny()), std::min(z0 + size - o[2], map->nz())};
+        for (int ix = b0[0]; ix < b1[0]; ++ix)
+            for (int iy = b0[1]; iy < b1[1]; ++iy)
+                for (int iz = b0[2]; iz < b1[2]; ++iz) {
                     uint8_t& v = map->at(ix, iy, iz);
                     v = (uint8_t)((v & ~2u) | (occupied ? 4u : 0u));  // observed; occupied or free
                 }
@@ -67,12 +68,20 @@ struct Walker {
 
 }  // namespace
 
+// sanity limits of the readers: a file outside them is refused, not allocated
+static const double kMinRes = 1e-4, kMaxRes = 1e4;           // metres per voxel
+static const long long kMaxVoxels = 1LL << 31;               // bytes of the dense grid (2 GiB)
+
 // bit0 = occupied (bit2) dilated by `inflate` metres per axis (separable box dilation)
 static void inflateOccupied(mapManager::occMap& m, const double inflate[3]) {
     const double res = m.getRes();
     const int n[3] = {m.nx(), m.ny(), m.nz()};
     mapManager::occMap* map = &m;
-    const int r[3] = {(int)std::ceil(inflate[0] / res - 1e-9), (int)std::ceil(inflate[1] / res - 1e-9), (int)std::ceil(inflate[2] / res - 1e-9)};
+    int r[3];
+    for (int a = 0; a < 3; ++a) {   // a radius beyond the map's extent changes nothing: clamped (and never out of int range)
+        const double ra = std::ceil(inflate[a] / res - 1e-9);
+        r[a] = !(ra > 0) ? 0 : (ra >= n[a] ? n[a] : (int)ra);
+    }
     std::vector<uint8_t> cur((size_t)n[0] * n[1] * n[2]), nxt(cur.size());
     for (size_t i = 0; i < cur.size(); ++i) cur[i] = (map->voxels()[i] & 4u) ? 1 : 0;
     auto idx = [&](int x, int y, int z) { return ((size_t)x * n[1] + y) * n[2] + z; };
@@ -110,7 +119,7 @@ std::shared_ptr<mapManager::occMap> loadOctomapBt(const std::string& path, const
         else if (line.rfind("res", 0) == 0) res = std::atof(line.c_str() + 3);
         else if (line.rfind("data", 0) == 0) { data = true; break; }
     }
-    if (!data || size < 0 || !(res > 0)) return nullptr;
+    if (!data || size < 0 || !(res >= kMinRes && res <= kMaxRes)) return nullptr;
 
     Walker w1;
     w1.p = buf.data() + pos;
@@ -134,6 +143,7 @@ std::shared_ptr<mapManager::occMap> loadOctomapBt(const std::string& path, const
         o[a] = w1.kmin[a] - margin;
         n[a] = w1.kmax[a] - w1.kmin[a] + 1 + 2 * margin;
     }
+    if (margin < 0 || margin > 4096 || (long long)n[0] * n[1] * n[2] > kMaxVoxels) return nullptr;   // a dense byte grid of that extent is not a map
     auto map = std::make_shared<mapManager::occMap>(n[0], n[1], n[2], Eigen::Vector3d(o[0] * res, o[1] * res, o[2] * res), res);
     std::fill(map->voxels().begin(), map->voxels().end(), (uint8_t)2);  // everything unknown until observed
     Walker w2;
@@ -153,7 +163,7 @@ std::shared_ptr<mapManager::occMap> loadOctomapBt(const std::string& path, const
 std::shared_ptr<mapManager::occMap> loadPcdAscii(const std::string& path, double res, const double inflate[3], int margin,
                                                  long long* pointsRead) {
     std::ifstream f(path);
-    if (!f || !(res > 0)) return nullptr;
+    if (!f || !(res >= kMinRes && res <= kMaxRes) || margin < 0 || margin > 4096) return nullptr;
     std::string line;
     long long declared = -1;
     bool ascii = false, xyzFirst = false;
@@ -166,7 +176,7 @@ std::shared_ptr<mapManager::occMap> loadPcdAscii(const std::string& path, double
     std::vector<double> pts;
     double x, y, z;
     while (std::getline(f, line)) {
-        if (std::sscanf(line.c_str(), "%lf %lf %lf", &x, &y, &z) == 3 && std::isfinite(x) && std::isfinite(y) && std::isfinite(z)) {
+        if (std::sscanf(line.c_str(), "%lf %lf %lf", &x, &y, &z) == 3 && std::fabs(x) / res < 1e9 && std::fabs(y) / res < 1e9 && std::fabs(z) / res < 1e9) {
             pts.push_back(x); pts.push_back(y); pts.push_back(z);
         }
     }
@@ -182,6 +192,7 @@ std::shared_ptr<mapManager::occMap> loadPcdAscii(const std::string& path, double
         }
     long long n[3];
     for (int a = 0; a < 3; ++a) { lo[a] -= margin; n[a] = hi[a] - lo[a] + 1 + margin; if (n[a] > 4096) return nullptr; }
+    if (n[0] * n[1] * n[2] > kMaxVoxels) return nullptr;
     auto map = std::make_shared<mapManager::occMap>((int)n[0], (int)n[1], (int)n[2], Eigen::Vector3d(lo[0] * res, lo[1] * res, lo[2] * res), res);
     for (long long i = 0; i < np; ++i) {
         const int ix = (int)((long long)std::floor(pts[3 * i] / res) - lo[0]), iy = (int)((long long)std::floor(pts[3 * i + 1] / res) - lo[1]),
