@@ -152,3 +152,98 @@ def test_bad_arguments_return_codes_and_keep_the_handle_usable(raw):
     assert L.vigo_optimize(h, 2, 32, dptr(ctrl), NULL, NULL, NULL, NULL, NULL, 0, NULL, NULL, dptr(st), NULL, NULL, NULL) == 0
     torch.cuda.synchronize()
     assert (st.cpu().numpy() != 77).all() and bool(torch.isfinite(ctrl).all())
+
+
+def test_extreme_values_in_device_data_do_not_fault(raw):
+    """NaN, +-inf, +-1e300 and denormals inside the DEVICE arrays (which the host cannot validate): every kernel
+    must run to completion with in-range indexing — positions that are not finite or not in the map count as
+    outside (occupied / unknown, the contract of include/vigo.h), solver statuses are lbfgs error codes."""
+    L, h = raw
+    dev = torch.device("cuda", 0)
+    vox = torch.zeros(16, 16, 40, dtype=torch.uint8, device=dev)
+    origin = (C.c_double * 3)(0, 0, 0)
+    assert L.vigo_set_grid(h, 16, 16, 40, origin, 0.1, dptr(vox)) == 0
+    bad = [float("nan"), float("inf"), -float("inf"), 1e300, -1e300, 5e-324, -2.5e9, 2147483648.0 * 0.1, 0.5]
+    pts = torch.tensor([[a, b, c] for a in bad for b in (0.5, bad[0], bad[3]) for c in (0.5, bad[1])], dtype=torch.float64, device=dev)
+    Q = pts.shape[0]
+    out = torch.full((Q,), 9, dtype=torch.uint8, device=dev)
+    for which in (0, 1):
+        assert L.vigo_query_points(h, which, Q, dptr(pts), dptr(out)) == 0
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        assert set(o.tolist()) <= {0, 1}
+        inside = ((pts >= 0) & (pts < torch.tensor([1.6, 1.6, 4.0], device=dev))).all(dim=1).cpu().numpy()
+        assert (o[~inside] == 1).all() and (o[inside] == 0).all()
+    # ESDF sampler: clamps to the lattice, never reads outside it
+    f32 = torch.rand(8, 8, 8, dtype=torch.float32, device=dev)
+    assert L.vigo_set_esdf(h, 8, 8, 8, origin, 0.1, dptr(f32)) == 0
+    dq = torch.zeros(Q, dtype=torch.float64, device=dev)
+    gq = torch.zeros(Q, 3, dtype=torch.float64, device=dev)
+    assert L.vigo_esdf_query(h, Q, dptr(pts), dptr(dq), dptr(gq)) == 0
+    # box sweep at the same positions
+    box = (C.c_double * 3)(0.4, 0.4, 0.2)
+    assert L.vigo_box_collision_points(h, Q, dptr(pts), box, 0.1, dptr(out)) == 0
+    torch.cuda.synchronize()
+    assert set(out.cpu().numpy().tolist()) <= {0, 1}
+    # gates, spline evaluation, cost/gradient and the solver on control points seeded with the same values
+    B, N = len(bad), 32
+    ctrl = torch.zeros(B, N, 3, dtype=torch.float64, device=dev)
+    ctrl[:, :, 0] = torch.arange(N, dtype=torch.float64, device=dev) * 0.04 + 0.1
+    ctrl[:, :, 1] = 0.8
+    ctrl[:, :, 2] = 1.0
+    for b, v in enumerate(bad):
+        ctrl[b, 10 + b, b % 3] = v
+    flag = torch.full((B,), 9, dtype=torch.uint8, device=dev)
+    first = torch.zeros(B, dtype=torch.int32, device=dev)
+    assert L.vigo_traj_collision(h, B, N, dptr(ctrl), 0.025, dptr(flag), dptr(first)) == 0
+    pt = torch.zeros(B, N, dtype=torch.uint8, device=dev)
+    ln = torch.zeros(B, N, dtype=torch.uint8, device=dev)
+    assert L.vigo_ctrl_occupancy(h, B, N, dptr(ctrl), dptr(pt), dptr(ln)) == 0
+    obs = torch.tensor([[0.5, 0.8, 1.0, float("nan"), 1e300, 0.0, float("inf"), 0.5, 0.5],
+                        [float("nan"), 0.8, 1.0, 0.1, 0.0, 0.0, 0.5, 0.5, 0.5]], dtype=torch.float64, device=dev)
+    assert L.vigo_traj_dynamic_collision(h, B, N, dptr(ctrl), 0.025, NULL, dptr(obs), 2, dptr(flag)) == 0
+    times = torch.tensor([0.0, 0.3, float("nan"), float("inf"), -1e300, 1e300], dtype=torch.float64, device=dev)
+    ev = torch.zeros(B, 6, 3, dtype=torch.float64, device=dev)
+    for deriv in (0, 1, 2):
+        assert L.vigo_bspline_eval(h, B, N, dptr(ctrl), deriv, 6, dptr(times), dptr(ev)) == 0
+    goff = (torch.arange(B * N + 1, dtype=torch.int32, device=dev) // 4).contiguous()   # a guide pair every 4th point
+    G = int(goff[-1].item())
+    gpv = torch.rand(G, 6, dtype=torch.float64, device=dev)
+    gpv[::3, 0] = float("nan")
+    gpv[1::3, 4] = float("inf")
+    gunk = torch.zeros(G, dtype=torch.uint8, device=dev)
+    assert L.vigo_guides_unknown(h, G, dptr(gpv), dptr(gunk)) == 0
+    cost = torch.zeros(B, dtype=torch.float64, device=dev)
+    grad = torch.zeros(B, N - 6, 3, dtype=torch.float64, device=dev)
+    assert L.vigo_cost_grad(h, B, N, dptr(ctrl), dptr(goff), dptr(gpv), dptr(gunk), NULL, dptr(obs), 2, NULL, dptr(cost), dptr(grad), NULL) == 0
+    st = torch.full((B,), 77, dtype=torch.int32, device=dev)
+    work = ctrl.clone()
+    assert L.vigo_optimize(h, B, N, dptr(work), dptr(goff), dptr(gpv), dptr(gunk), NULL, dptr(obs), 2, NULL, NULL, dptr(st), NULL, NULL, NULL) == 0
+    torch.cuda.synchronize()
+    assert (st.cpu().numpy() != 77).all()
+    # fit, min-snap and the corridor checker
+    fit_in = torch.rand(4, 12, 3, dtype=torch.float64, device=dev)
+    fit_in[0, 3, 1] = float("nan"); fit_in[1, 0, 0] = float("inf"); fit_in[2, 5, 2] = 1e300
+    fit_out = torch.zeros(4, 14, 3, dtype=torch.float64, device=dev)
+    assert L.vigo_bspline_fit(h, 4, 12, 0.1, dptr(fit_in), NULL, dptr(fit_out)) == 0
+    wp = torch.rand(5, 6, 3, dtype=torch.float64, device=dev) * 4
+    wp[0, 2, 0] = float("nan"); wp[1, 1, 1] = float("inf"); wp[2, 3, 2] = 1e300; wp[3, 4] = wp[3, 3]
+    cor = torch.full((5, 5), 0.3, dtype=torch.float64, device=dev)
+    cor[4, 1] = float("nan")
+    co = torch.zeros(5, 5, 3, 8, dtype=torch.float64, device=dev)
+    kn = torch.zeros(5, 6, dtype=torch.float64, device=dev)
+    ms = torch.full((5,), 77, dtype=torch.int32, device=dev)
+    assert L.vigo_minsnap(h, 5, 6, 7, 4, 4, 1.0, 8.0, dptr(wp), dptr(cor), NULL, dptr(co), dptr(kn), dptr(ms)) == 0
+    torch.cuda.synchronize()
+    assert (ms[:3].cpu().numpy() < 0).all()                 # non-finite waypoints are reported, not solved
+    seg = torch.zeros(6, 3, 8, dtype=torch.float64, device=dev)
+    seg[:, :, 0] = 0.8
+    seg[0, 0, 1] = float("nan"); seg[1, 1, 7] = float("inf"); seg[2, 2, 3] = 1e300; seg[3, 0, 1] = -1e300; seg[4, 0, 1] = 5e-324
+    ns = torch.tensor([100, 100, 100, 100, 100, 0], dtype=torch.int32, device=dev)
+    dT = torch.tensor([0.01, 0.01, 0.01, float("nan"), 1e300, 0.01], dtype=torch.float64, device=dev)
+    cf = torch.full((6,), 9, dtype=torch.uint8, device=dev)
+    c1 = torch.zeros(6, dtype=torch.int32, device=dev)
+    c2 = torch.zeros(6, dtype=torch.int32, device=dev)
+    assert L.vigo_corridor_check(h, 6, 7, dptr(seg), dptr(ns), dptr(dT), box, 0.1, dptr(cf), dptr(c1), dptr(c2)) == 0
+    torch.cuda.synchronize()
+    assert set(cf.cpu().numpy().tolist()) <= {0, 1}

@@ -73,7 +73,7 @@ __device__ __forceinline__ void axis_keys(double lo, int num, double map_res, do
         k[i] = 0;
         if (i <= num) {
             const float q = (float)(lo + i * map_res);
-            out |= (q < bmin) || (q > bmax);                       // PO.cpp:572-577 metric bounds
+            out |= !(q >= bmin && q <= bmax);                      // PO.cpp:572-577 metric bounds (a NaN pose is outside)
             const int kk = (int)floor(rf * (double)q) - key0;
             out |= (kk < 0) || (kk >= dim);                        // no node there: unknown -> occupied
             k[i] = kk;
@@ -136,15 +136,15 @@ __device__ __forceinline__ bool box_sweep(const GridView& g, const SweepConst& C
     // a collision box of more than 3 map cells per axis: the reference's walk as written
     for (int xi = 0; xi <= xNum && !hit; ++xi) {
         const float qx = (float)(xmin + xi * map_res);
-        const bool x_out = (qx < g.bmin[0]) || (qx > g.bmax[0]);
+        const bool x_out = !(qx >= g.bmin[0] && qx <= g.bmax[0]);
         const int kx = (int)floor(rf * (double)qx) - g.key0[0];
         for (int yi = 0; yi <= yNum && !hit; ++yi) {
             const float qy = (float)(ymin + yi * map_res);
-            const bool y_out = (qy < g.bmin[1]) || (qy > g.bmax[1]);
+            const bool y_out = !(qy >= g.bmin[1] && qy <= g.bmax[1]);
             const int ky = (int)floor(rf * (double)qy) - g.key0[1];
             for (int zi = 0; zi <= zNum; ++zi) {
                 const float qz = (float)(zmin + zi * map_res);
-                if (x_out || y_out || (qz < g.bmin[2]) || (qz > g.bmax[2])) { hit = true; break; }
+                if (x_out || y_out || !(qz >= g.bmin[2] && qz <= g.bmax[2])) { hit = true; break; }
                 const int kz = (int)floor(rf * (double)qz) - g.key0[2];
                 if ((grid_bits_at(g, kx, ky, kz) >> 1) != 0) { hit = true; break; }  // outside -> 7 -> collides
             }

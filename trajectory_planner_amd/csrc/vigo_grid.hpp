@@ -25,11 +25,17 @@ __device__ __forceinline__ unsigned grid_plane_at(const GridView& g, int plane, 
     return (g.planes[(size_t)plane * g.plane_words + w] >> ((unsigned)iz & 31u)) & 1u;
 }
 
-// posToIndex: floor((p - origin) / res)
+// posToIndex: floor((p - origin) / res).  The range test is made on the double, so a NaN coordinate (which the
+// conversion would turn into index 0) and anything beyond int range are outside the map like on the CPU.
+__device__ __forceinline__ int grid_index(double p, double origin, double res, int n) {
+    const double f = floor((p - origin) / res);
+    return (f >= 0.0 && f < (double)n) ? (int)f : -1;
+}
+
 __device__ __forceinline__ unsigned grid_plane_pos(const GridView& g, int plane, double x, double y, double z) {
-    const int ix = (int)floor((x - g.origin[0]) / g.res);
-    const int iy = (int)floor((y - g.origin[1]) / g.res);
-    const int iz = (int)floor((z - g.origin[2]) / g.res);
+    const int ix = grid_index(x, g.origin[0], g.res, g.nx);
+    const int iy = grid_index(y, g.origin[1], g.res, g.ny);
+    const int iz = grid_index(z, g.origin[2], g.res, g.nz);
     return grid_plane_at(g, plane, ix, iy, iz);
 }
 
