@@ -61,8 +61,13 @@ public:
      * un-normalised local time, (deg+1) per segment; knots must be getTimeKnot()'s */
     void installSolution(const std::vector<double>& x, const std::vector<double>& y, const std::vector<double>& z);
     bool solve();   // the reference's solve() is void and silently keeps a stale solution on failure
-    /* all three axes hold a polynomial (false until the first success: an infeasible first corridor leaves nothing to sample) */
-    bool hasSolution() const { return !xSol_.empty() && !ySol_.empty() && !zSol_.empty(); }
+    /* all three axes hold a polynomial OF THE CURRENT PATH (false until the first success, and again after
+     * updatePath() changed the number of segments: a stale polynomial of another path cannot be sampled on
+     * this path's knots) */
+    bool hasSolution() const {
+        const size_t want = paramDim_ > 0 ? (size_t)paramDim_ : 0;
+        return want > 0 && xSol_.size() == want && ySol_.size() == want && zSol_.size() == want;
+    }
     pose getPose(double t);
     void getTrajectory(std::vector<pose>& trajectory, double delT);
     std::vector<double>& getTimeKnot();

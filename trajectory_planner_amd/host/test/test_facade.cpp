@@ -268,6 +268,62 @@ int main() {
         CHECK(t2.size() == trajs[3].size() && worst < 1e-6 && solo->isValid() == res[3], "batch plan == single makePlan (device QP == host QP)");
     }
 
+    // ---- degenerate inputs: the classes answer false / "not found", never crash ----
+    {
+        const double nan = std::nan("");
+        bsplineTraj fresh(makeParams());
+        CHECK(!fresh.makePlan(), "makePlan without a map and a path is false");
+        fresh.setMap(map);
+        CHECK(!fresh.makePlan(), "makePlan without a path is false");
+        nav_msgs::Path none, three = straight(-3.0, 2.5, -2.5, 2.5, 1.0, 0.25), same = straight(-3.0, 2.5, -3.0, 2.5, 1.0, 0.25);
+        three.poses.resize(3);
+        CHECK(!fresh.updatePath(none, cond), "updatePath refuses an empty path");
+        {   // 3 poses: the prologue may interpolate them to 4+ fit points (BT.cpp:279-331); either way no exit(0)
+            const bool up3 = fresh.updatePath(three, cond);
+            CHECK(!up3 || fresh.getControlPoints().cols() >= 6, "updatePath of 3 poses: refused, or a spline of >= 6 control points");
+        }
+        nav_msgs::Path poisoned = straight(-3.0, 2.5, 3.0, 2.5, 1.0, 0.25);
+        poisoned.poses[4].pose.position.y = nan;
+        const bool upNan = fresh.updatePath(poisoned, cond);
+        const bool planNan = upNan && fresh.makePlan();
+        CHECK(!planNan, "a NaN waypoint never yields a plan");
+        (void)fresh.updatePath(same, cond);
+        (void)fresh.makePlan();
+        (void)fresh.getPose(0.3);
+        std::vector<bsplineTraj*> withNull{&fresh, nullptr};
+        // batch entry points with unprepared planners
+        bsplineTraj idle(makeParams());
+        std::vector<bsplineTraj*> two{&fresh, &idle};
+        std::vector<bool> r2 = bsplineTraj::makePlanBatch(two);
+        CHECK(r2.size() == 2 && !r2[1], "makePlanBatch reports an unprepared planner as failed");
+        CHECK(bsplineTraj::makePlanBatch(std::vector<bsplineTraj*>{}).empty(), "makePlanBatch of nothing");
+
+        ros::NodeHandle nh;
+        nh.setParam("collision_box", std::vector<double>{0.4, 0.4, 0.2});
+        nh.setParam("map_resolution", 0.2);
+        nh.setParam("sample_delta_time", 0.1);
+        nh.setParam("traj_timeout", 0.2);
+        trajPlanner::polyTrajOctomap poly(nh);
+        poly.setMap(map);
+        std::vector<trajPlanner::pose> traj;
+        poly.makePlan(traj, 0.1);                                    // no path at all
+        CHECK(traj.empty() && !poly.isValid(), "polyTrajOctomap without a path plans nothing");
+        poly.updatePath(std::vector<trajPlanner::pose>{{1, 2, 1}});
+        poly.makePlan(traj, 0.1);
+        CHECK(traj.size() == 1, "a single waypoint is its own trajectory (PO.cpp:229-233)");
+        poly.updatePath(std::vector<trajPlanner::pose>{{1, 2, 1}, {1, 2, 1}, {3, 2, 1}});      // coincident waypoints
+        poly.makePlan(traj, 0.1);
+        bool fin = true;
+        for (const auto& q : traj) fin = fin && std::isfinite(q.x) && std::isfinite(q.y) && std::isfinite(q.z);
+        CHECK(fin, "coincident waypoints give a finite trajectory (min-snap or the piecewise-linear fallback)");
+        poly.updatePath(std::vector<trajPlanner::pose>{{1, 2, 1}, {nan, 2, 1}, {3, 2, 1}});
+        poly.makePlan(traj, 0.1);
+        CHECK(!poly.isValid() || traj.empty(), "a NaN waypoint never yields a valid min-snap plan");
+        std::vector<trajPlanner::polyTrajOctomap*> pnone;
+        std::vector<std::vector<trajPlanner::pose>> tn;
+        CHECK(trajPlanner::polyTrajOctomap::makePlanBatch(pnone, tn).empty(), "polyTrajOctomap::makePlanBatch of nothing");
+    }
+
     // ---- randomised stress (VIGO_FACADE_FUZZ=<rounds>, default 3): random box worlds, random straight paths with
     //      free end points, dynamic obstacles on a third of the planners.  No success rate is demanded (a random
     //      world may wall a path in); what is demanded: no crash, and every plan reported successful is collision
