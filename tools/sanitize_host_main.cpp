@@ -2,6 +2,7 @@
 #include <trajectory_planner/polyTrajSolver.h>
 #include <trajectory_planner/bspline.h>
 #include <trajectory_planner/path_search/astarOcc.h>
+#include <cmath>
 #include <cstdio>
 #include <random>
 #include <string>
@@ -58,6 +59,43 @@ int main(int argc, char** argv) {
             const bool found = a.AstarSearch(0.1, Eigen::Vector3d(-2.0, 2.0 * U(rng), 1.0), Eigen::Vector3d(2.0, 2.0 * U(rng), 1.0));
             if (found && a.getPath().size() < 2) ++fails;
         }
+    }
+    // A* on random box worlds: a found path is connected on the 26-neighbourhood lattice, stays out of inflated
+    // voxels and ends next to the (possibly shifted, AS.cpp:58-102) end points; hostile queries (identical,
+    // outside the pool, NaN) come back false
+    {
+        long found = 0, asked = 0, broken = 0;
+        for (int world = 0; world < 12; ++world) {
+            auto m = std::make_shared<mapManager::occMap>(80, 80, 24, Eigen::Vector3d(-4.0, -4.0, 0.0), 0.1);
+            const int nb = 2 + world;
+            for (int b = 0; b < nb; ++b) {
+                const int cx = 10 + (int)(30 * (U(rng) + 1)), cy = 10 + (int)(30 * (U(rng) + 1)), hx = 1 + (int)(4 * std::fabs(U(rng))), hy = 1 + (int)(6 * std::fabs(U(rng)));
+                for (int x = std::max(0, cx - hx); x < std::min(80, cx + hx); ++x)
+                    for (int y = std::max(0, cy - hy); y < std::min(80, cy + hy); ++y)
+                        for (int z = 0; z < 24; ++z) m->at(x, y, z) |= 5;
+            }
+            AStar a;
+            a.initGridMap(m, Eigen::Vector3i(100, 100, 100), 0.0, 2.0);
+            for (int k = 0; k < 40; ++k) {
+                const Eigen::Vector3d s(3.5 * U(rng), 3.5 * U(rng), 0.5 + 1.0 * std::fabs(U(rng))), e(3.5 * U(rng), 3.5 * U(rng), 0.5 + 1.0 * std::fabs(U(rng)));
+                ++asked;
+                if (!a.AstarSearch(0.1, s, e)) continue;
+                ++found;
+                const std::vector<Eigen::Vector3d> path = a.getPath();
+                bool ok = path.size() >= 1;
+                for (size_t i = 0; i < path.size() && ok; ++i) {
+                    if (i > 0 && (path[i] - path[i - 1]).norm() > 0.1 * std::sqrt(3.0) + 1e-9) ok = false;
+                    if (i > 0 && i + 1 < path.size() && m->isInflatedOccupied(path[i])) ok = false;
+                }
+                if (!ok) { ++broken; ++fails; }
+            }
+            const double nan = std::nan("");
+            if (a.AstarSearch(0.1, Eigen::Vector3d(60, 0, 1), Eigen::Vector3d(0, 0, 1))) ++fails;             // outside the pool
+            if (a.AstarSearch(0.1, Eigen::Vector3d(nan, 0, 1), Eigen::Vector3d(0, 0, 1))) ++fails;
+            (void)a.AstarSearch(0.1, Eigen::Vector3d(0.33, 0.2, 1), Eigen::Vector3d(0.33, 0.2, 1));            // identical ends
+            (void)a.AstarSearch(0.0, Eigen::Vector3d(0, 0, 1), Eigen::Vector3d(1, 0, 1));                       // zero step
+        }
+        std::printf("A*: %ld of %ld random queries found a path, %ld broken\n", found, asked, broken);
     }
     std::printf("%s\n", fails ? "FAILED" : "sanitizer run complete, no failures");
     return fails;
