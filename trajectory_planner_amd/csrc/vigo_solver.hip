@@ -772,6 +772,24 @@ __device__ __forceinline__ int trial_interval(double& xt, double& xf, double& xd
 #ifndef VIGO_TWOLOOP_MARKSTEIN
 #define VIGO_TWOLOOP_MARKSTEIN 1
 #endif
+// dev builds only (-DVIGO_PROFILE_SECTIONS=1, tools/exp_sections.py): shader-clock totals of the sections of an
+// iteration, written over out_x[b][0..9] — never defined in the shipped library
+#ifndef VIGO_PROFILE_SECTIONS
+#define VIGO_PROFILE_SECTIONS 0
+#endif
+#if VIGO_PROFILE_SECTIONS
+#define VIGO_TICK(acc)                                                   \
+    do {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        const long long now_ = (long long)__builtin_readcyclecounter();  \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        acc += (double)(now_ - tick_);                                   \
+        tick_ = now_;                                                    \
+    } while (0)
+#else
+#define VIGO_TICK(acc) do { } while (0)
+#endif
+
 template <typename T, int GROUP, int PPL, bool FAST>
 __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevConst* __restrict__ Kp) {
     const DevConst& K = *Kp;  // uniform address: scalar loads at the use sites, not 100+ live SGPRs
@@ -795,6 +813,10 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
 
     LaneProblem<T, PPL> Q;
     load_problem<T, GROUP, PPL>(A, K, b, lane % GROUP, Q);
+#if VIGO_PROFILE_SECTIONS
+    long long tick_ = (long long)__builtin_readcyclecounter();
+    double t_eval = 0, t_ls = 0, t_upd = 0, t_two = 0, t_tail = 0, t_pre = 0, t_trial = 0, t_cal = 0;
+#endif
     // history column of each owned point.  Points that are not free (index < 3 or > N-4) read a
     // neighbour's column — finite data their zero d/g wipes out — and never write.
     HPair<T>* hl[PPL];
@@ -905,7 +927,9 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
                         x[q][a] = FAST ? fmaT((T)step, d[q][a], xp[q][a]) : xp[q][a] + (T)step * d[q][a];
             }
 
+            VIGO_TICK(t_pre);
             fx = eval_cost_grad<T, GROUP, PPL, FAST>(K, Q, x, d, g, sums);  // the only evaluation site (LB:828, :1132)
+            VIGO_TICK(t_eval);
             ++evals;
             if (first) break;
 
@@ -929,7 +953,9 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
             double axf = mod ? xf - xt * dgtest : xf, axd = mod ? xd - dgtest : xd;
             double ayf = mod ? yf - yt * dgtest : yf, ayd = mod ? yd - dgtest : yd;
             const double atf = mod ? fx - step * dgtest : fx, atd = mod ? dg - dgtest : dg;
+            VIGO_TICK(t_ls);
             uinfo = trial_interval(xt, axf, axd, yt, ayf, ayd, step, atf, atd, stmin, stmax, brackt);
+            VIGO_TICK(t_trial);
             xf = mod ? axf + xt * dgtest : axf;
             yf = mod ? ayf + yt * dgtest : ayf;
             xd = mod ? axd + dgtest : axd;
@@ -942,6 +968,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
             }
         }
 
+        VIGO_TICK(t_ls);
         double xnorm = sqrt(sums[5]), gnorm = sqrt(sums[6]);
         if (first) {
             first = false;
@@ -1150,6 +1177,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
                 for (int a = 0; a < 3; ++a) bad |= !(d[q][a] == d[q][a]);
             return bad;
         };
+        VIGO_TICK(t_upd);
         if (VIGO_TWOLOOP_STEADY && PPL == 1 && bound == kMaxMem && !__any(last != __builtin_amdgcn_readfirstlane(last))) {
             if (__any(two_loop(std::true_type{}))) {
                 // a dividend outside the range Markstein's sequence is proven for (or a NaN): the same
@@ -1164,6 +1192,7 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
         } else {
             two_loop(std::false_type{});
         }
+        VIGO_TICK(t_two);
         if (REG1) {
             // the age-1 pair turns age 2 for the next two-loop: it leaves the registers for the LDS
             // ring (overwriting the pair that would be age m), the new pair takes its place
@@ -1189,6 +1218,8 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
         }
         sums[4] = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(g, d));  // dginit of the next line search (LB:746)
         step = 1.0;  // LB:1321
+        VIGO_TICK(t_tail);
+        VIGO_TICK(t_cal);    // back-to-back: the cost of one probe
     }
 
     // results.  On success / convergence / iteration cap the last evaluated point is x itself.
@@ -1200,6 +1231,13 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
             dst[0] = (double)x[q][0]; dst[1] = (double)x[q][1]; dst[2] = (double)x[q][2];
         }
     }
+#if VIGO_PROFILE_SECTIONS
+    if (lane % GROUP == 0 && A.out_x) {
+        double* o = A.out_x + (size_t)b * NI * 3;
+        o[0] = t_eval; o[1] = t_ls; o[2] = t_upd; o[3] = t_two; o[4] = t_tail; o[5] = (double)k; o[6] = (double)evals;
+        o[7] = t_pre; o[8] = t_trial; o[9] = t_cal;
+    }
+#endif
     if (lane % GROUP == 0) {
         if (A.out_status) A.out_status[b] = ret;
         if (A.out_fx) A.out_fx[b] = fx;
