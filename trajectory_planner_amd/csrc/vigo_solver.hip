@@ -937,12 +937,18 @@ __global__ void __launch_bounds__(kWave, 1) k_optimize(SolveArgs A, const DevCon
             const double ftest1 = finit + step * dgtest;
             ++count;
 
-            if (brackt && ((step <= stmin || stmax <= step) || uinfo != 0)) { ls = LBERR_ROUNDING_ERROR; break; }
-            if (step == stpmax && fx <= ftest1 && dg <= dgtest) { ls = LBERR_MAXIMUMSTEP; break; }
-            if (step == stpmin && (ftest1 < fx || dgtest <= dg)) { ls = LBERR_MINIMUMSTEP; break; }
-            if (brackt && (stmax - stmin) <= K.xtol * stmax) { ls = LBERR_WIDTHTOOSMALL; break; }
-            if (K.max_linesearch <= count) { ls = LBERR_MAXIMUMLINESEARCH; break; }
-            if (fx <= ftest1 && fabs(dg) <= K.gtol * (-dginit)) { ls = count; break; }
+            // LB:832-866: six exits tested in order, the first that holds wins.  Evaluated as one select chain
+            // in reverse order and ONE branch (six exec-mask branches cost more issue slots than the compares)
+            {
+                int code = 0;
+                if (fx <= ftest1 && fabs(dg) <= K.gtol * (-dginit)) code = count;                      // LB:862-866 (count >= 1)
+                if (K.max_linesearch <= count) code = LBERR_MAXIMUMLINESEARCH;                         // LB:857-860
+                if (brackt && (stmax - stmin) <= K.xtol * stmax) code = LBERR_WIDTHTOOSMALL;           // LB:852-855
+                if (step == stpmin && (ftest1 < fx || dgtest <= dg)) code = LBERR_MINIMUMSTEP;         // LB:847-850
+                if (step == stpmax && fx <= ftest1 && dg <= dgtest) code = LBERR_MAXIMUMSTEP;          // LB:842-845
+                if (brackt && ((step <= stmin || stmax <= step) || uinfo != 0)) code = LBERR_ROUNDING_ERROR;   // LB:837-840
+                if (code != 0) { ls = code; break; }
+            }
 
             const double cmin = K.ftol <= K.gtol ? K.ftol : K.gtol;
             if (stage1 && fx <= ftest1 && cmin * dginit <= dg) stage1 = 0;
