@@ -340,13 +340,14 @@ def test_parameter_variations_stay_bit_exact(vigo_handle, small_world):
     assert (terms.cpu().numpy()[:, 3] > 0).any() and len(np.unique(g["status"])) >= 2
 
 
-@pytest.mark.parametrize("scale", [1e-80, 1e-120, float("nan")])
+@pytest.mark.parametrize("scale", [1e-25, 1e-40, 1e-80, 1e-120, float("nan")])
 def test_two_loop_division_fallback_is_exact(vigo_handle, small_world, scale):
     """The steady-state two-loop divides by ys with Markstein's exact reciprocal sequence, proven for operands
     within 2^+-500; beyond that (or on a NaN) it repeats the recursion with true divisions.  Control points
-    scaled to 1e-80 / 1e-120 put the dividends (~ scale^2) far below 2^-500 while three of the 40 solves still
-    run all 40 iterations, i.e. through the steady-state path with a full history; a NaN control point covers
-    the other trigger.  Results stay bit-identical to the emulation-mode oracle, which always divides."""
+    scaled by 1e-25 / 1e-40 keep the dividends (~ scale^2) inside that range (the reciprocal path runs), 1e-80 /
+    1e-120 put them far below 2^-500 (the fallback runs) while some of the 40 solves still run all 40
+    iterations, i.e. through the steady-state path with a full history; a NaN control point covers the other
+    trigger.  Results stay bit-identical to the emulation-mode oracle, which always divides."""
     v = vigo_handle
     P = default_params()
     P.max_iterations = 40
