@@ -509,7 +509,8 @@ int vigo_box_collision_points(vigo_handle_t h, int64_t M, const double* pts, con
 
 int vigo_set_esdf(vigo_handle_t h, int nx, int ny, int nz, const double origin[3], double res, const float* dist_dev) {
     if (!h || !dist_dev || !origin || nx < 2 || ny < 2 || nz < 2 || !(res > 0)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_esdf: bad argument");
-    size_t bytes = (size_t)nx * ny * nz * sizeof(float);
+    if ((long long)nx * ny * nz > (1LL << 33)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_esdf: lattice too large");
+    size_t bytes = vigo::esdf_bricked_floats(nx, ny, nz) * sizeof(float);
     if (bytes > h->esdf_capacity) {
         if (h->esdf) (void)hipFree(h->esdf);
         h->esdf = nullptr;
@@ -517,9 +518,10 @@ int vigo_set_esdf(vigo_handle_t h, int nx, int ny, int nz, const double origin[3
         VIGO_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->esdf), bytes));
         h->esdf_capacity = bytes;
     }
-    VIGO_HIP(h, hipMemcpyAsync(h->esdf, dist_dev, bytes, hipMemcpyDeviceToDevice, h->stream));
+    VIGO_HIP(h, (hipError_t)vigo::launch_esdf_brick(h->stream, nx, ny, nz, dist_dev, h->esdf));   // row-major -> 4x4x4 bricks
     h->esdf_view.dist = h->esdf;
     h->esdf_view.nx = nx; h->esdf_view.ny = ny; h->esdf_view.nz = nz;
+    h->esdf_view.nby = (ny + 3) / 4; h->esdf_view.nbz = (nz + 3) / 4;
     h->esdf_view.res = res;
     for (int a = 0; a < 3; ++a) h->esdf_view.origin[a] = origin[a];
     h->has_esdf = true;
