@@ -1,5 +1,6 @@
+"""dev: timing of 1 M uniformly random trilinear ESDF queries on a 256^3 lattice and of vigo_set_esdf (re-tiling into bricks)"""
 import json, os, sys, time
-R='/root/repo'; sys.path.insert(0,R)
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np, torch
 from trajectory_planner_amd import synth
 from trajectory_planner_amd.vigo import Vigo
