@@ -87,10 +87,20 @@ struct Tile {
     bool in_lds;
 };
 
+// Per-lane memory of the previous pose's lattice keys and verdict (k_corridor).  The verdict of the fast path is a
+// function of the per-axis keys alone; consecutive samples of a segment are ~0.1 mm apart against 100 mm voxels,
+// so the keys repeat for hundreds of samples and the 18 lookups are skipped whenever every lane of the wave
+// repeats its keys (a wave-uniform branch: results cannot depend on it).
+struct SweepMemo {
+    int kx[kAxisMax], ky[kAxisMax], kz[kAxisMax];
+    int nums;            // xNum | yNum << 8 | zNum << 16, -1 = nothing remembered
+    bool verdict;
+};
+
 // polyTrajOctomap::checkCollision(point3d) for one pose.  T != nullptr: look the voxels up in the LDS
 // tile when it holds them (it does by construction of the tile; the test costs six compares per pose).
 __device__ __forceinline__ bool box_sweep(const GridView& g, const SweepConst& C, float fx, float fy, float fz,
-                                          const Tile* T, const uint32_t* tile_words) {
+                                          const Tile* T, const uint32_t* tile_words, SweepMemo* memo = nullptr) {
     const double map_res = C.map_res, rf = C.rf;
     // PO.cpp:548-555
     const double xmin = fx - C.box[0] / 2, xmax = fx + C.box[0] / 2;
@@ -109,6 +119,16 @@ __device__ __forceinline__ bool box_sweep(const GridView& g, const SweepConst& C
         axis_keys(ymin, yNum, map_res, rf, g.bmin[1], g.bmax[1], g.key0[1], g.ny, ky, hit);
         axis_keys(zmin, zNum, map_res, rf, g.bmin[2], g.bmax[2], g.key0[2], g.nz, kz, hit);
         if (hit) return true;
+        if (memo) {
+            const int nums = xNum | (yNum << 8) | (zNum << 16);
+            bool same = nums == memo->nums;
+#pragma unroll
+            for (int i = 0; i < kAxisMax; ++i) same = same && kx[i] == memo->kx[i] && ky[i] == memo->ky[i] && kz[i] == memo->kz[i];
+            if (__all(same)) return memo->verdict;
+            memo->nums = nums;
+#pragma unroll
+            for (int i = 0; i < kAxisMax; ++i) { memo->kx[i] = kx[i]; memo->ky[i] = ky[i]; memo->kz[i] = kz[i]; }
+        }
         // keys grow with the lattice index: the tile holds all of them iff it holds the first and last
         const bool tiled = T && T->in_lds && kx[0] >= T->x0 && kx[xNum] < T->x0 + T->tx && ky[0] >= T->y0 &&
                            ky[yNum] < T->y0 + T->ty && (kz[0] >> 5) >= T->w0 && (kz[zNum] >> 5) < T->w0 + T->tw;
@@ -126,11 +146,13 @@ __device__ __forceinline__ bool box_sweep(const GridView& g, const SweepConst& C
                         if (zi <= zNum) any |= tile_words[col + (kz[zi] >> 5)] >> (kz[zi] & 31);
                 }
             }
+            if (memo) memo->verdict = (any & 1u) != 0;
             return (any & 1u) != 0;
         }
         for (int xi = 0; xi <= xNum; ++xi)
             for (int yi = 0; yi <= yNum; ++yi)
                 for (int zi = 0; zi <= zNum; ++zi) any |= grid_bits_at(g, kx[xi], ky[yi], kz[zi]) >> 1;  // unknown | occupied
+        if (memo) memo->verdict = any != 0;
         return any != 0;
     }
     // a collision box of more than 3 map cells per axis: the reference's walk as written
@@ -244,6 +266,11 @@ __global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A)
 
     // ---- sweep pass: box sweep per sample ----
     int my_first = 0x7fffffff, my_count = 0;
+    SweepMemo memo;
+    memo.nums = -1;
+    memo.verdict = false;
+#pragma unroll
+    for (int i = 0; i < kAxisMax; ++i) memo.kx[i] = memo.ky[i] = memo.kz[i] = 0;
     auto walk = [&](auto eval) {
         for (int c = tid; c < n_chunks; c += kBlock) {
             const int k0 = c * kChunk, k1 = min(n, k0 + kChunk);
@@ -252,7 +279,7 @@ __global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A)
                 double p[3];
                 eval(t, p);
                 const float fx = (float)p[0], fy = (float)p[1], fz = (float)p[2];  // pose2Octomap
-                const bool hit = box_sweep(g, A.sweep, fx, fy, fz, &T, tile_words);
+                const bool hit = box_sweep(g, A.sweep, fx, fy, fz, &T, tile_words, &memo);
                 if (hit) {
                     if (k < my_first) my_first = k;
                     ++my_count;
