@@ -45,13 +45,25 @@ try:
     vox, origin, res, wp, _ = c1.load_maze()
     cfg = [0.4, 0.4, 0.2, 0.2, 0.1, 1.0, 0.5, 0.8, 8.0, 100, 0.1, 0.0]
     c1.plan(vox, origin, res, wp, cfg)
-    ts = []
-    for _ in range(10):
+    ts, cold = [], []
+    for k in range(10):
+        # a path the previous call did not see (one waypoint moved by millimetres): the QP factorisation kept per
+        # host thread does not apply, this is the time of a first makePlan() on a new path
+        wp2 = np.array(wp, dtype=np.float64, copy=True)
+        wp2[3, 0] += 1e-3 * (k + 1)
+        traj, info = c1.plan(vox, origin, res, wp2, cfg)
+        cold.append(info[4])
+        # the fixture path again: same matrices as two calls ago, not as the last one -> also a fresh factorisation
         traj, info = c1.plan(vox, origin, res, wp, cfg)
         ts.append(info[4])
+    rep = []
+    for _ in range(10):   # the same path back to back: factorisation reused (what the corridor loop's later rounds see)
+        traj, info = c1.plan(vox, origin, res, wp, cfg)
+        rep.append(info[4])
     print(json.dumps({"config": "1: polyTrajOctomap makePlan, maze.bt, 8 waypoints (host QP + device sweep)", "valid": bool(info[0]),
                       "corridor_iterations": int(info[1]), "samples": int(info[2]), "makePlan_ms_median": float(np.median(ts)) * 1e3,
-                      "makePlan_ms_min": float(np.min(ts)) * 1e3}), flush=True)
+                      "makePlan_ms_min": float(np.min(ts)) * 1e3, "makePlan_ms_new_path_median": float(np.median(cold)) * 1e3,
+                      "makePlan_ms_same_path_again_median": float(np.median(rep)) * 1e3}), flush=True)
 except Exception as e:  # noqa
     print(json.dumps({"config": "1", "error": repr(e)}), flush=True)
 

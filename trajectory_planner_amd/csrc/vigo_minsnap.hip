@@ -455,6 +455,62 @@ __global__ void __launch_bounds__(kLanes) k_minsnap(MinsnapArgs A) {
             __syncthreads();
             const int maxIter = 50 * (nc + nf) + 100;
             int iter = 0;
+            int polished = 0;
+            // Once nothing is violated any more the primal point and the multipliers are recomputed from the
+            // working set itself (u = M^-1 (b_A + N H^-1 c), w = H^-1 (N'u - c)): the increments t z that carried
+            // w there leave it up to 1e-5 (relative) off the working set's face on long corridors (dozens of nearly
+            // degenerate partial steps) — feasible but measurably sub-optimal.  Same formulas as the host solver;
+            // should the polished point violate a box, the loop resumes from it.  Returns false when it keeps the
+            // carried point (empty or ill-conditioned working set, a negative multiplier).
+            auto polish = [&]() -> bool {
+                const int q = s_q;
+                if (q == 0) return false;
+                // Hn <- H^-1 c ; HN <- H^-1 N ; rhs <- b_A + N H^-1 c with b_A = N w - slack (w is the carried point)
+                for (int i = lane; i < nf; i += kLanes) {
+                    double hs = 0.0;
+                    for (int j = 0; j < nf; ++j) hs += Hinv[i * nf + j] * cvec[j * 3 + axis];
+                    Hn[i] = hs;
+                    for (int a = 0; a < q; ++a) {
+                        double h = 0.0;
+                        for (int j = 0; j < nf; ++j) h += Hinv[i * nf + j] * Nact[a * nf + j];
+                        HN[i * nf + a] = h;
+                    }
+                }
+                __syncthreads();
+                for (int idx = lane; idx < q * q; idx += kLanes) {
+                    const int a = idx / q, b = idx % q;
+                    double ms = 0.0;
+                    for (int i = 0; i < nf; ++i) ms += Nact[a * nf + i] * HN[i * nf + b];
+                    Mq[a * nf + b] = ms;
+                }
+                for (int a = lane; a < q; a += kLanes) {
+                    double mag;
+                    double rs = -slack_of(act[a], mag);
+                    for (int i = 0; i < nf; ++i) rs += Nact[a * nf + i] * (w[i] + Hn[i]);
+                    rhs[a] = rs;
+                }
+                __syncthreads();
+                if (lane == 0) {
+                    bool ok = chol_serial(Mq, q, nf);
+                    if (ok) {
+                        chol_solve_serial(Mq, q, nf, rhs);
+                        for (int a = 0; a < q; ++a) ok = ok && (rhs[a] >= 0.0);
+                    }
+                    s_drop = ok ? 1 : 0;
+                    if (ok) for (int a = 0; a < q; ++a) u[a] = rhs[a];
+                }
+                __syncthreads();
+                if (!s_drop) return false;
+                for (int i = lane; i < nf; i += kLanes) {
+                    double ws = -Hn[i];
+                    for (int a = 0; a < q; ++a) ws += HN[i * nf + a] * rhs[a];
+                    w[i] = ws;
+                }
+                __syncthreads();
+                refresh_xcur();
+                __syncthreads();
+                return true;
+            };
             while (nc > 0) {
                 // most violated constraint outside the working set
                 double worst = 0.0;
@@ -471,7 +527,10 @@ __global__ void __launch_bounds__(kLanes) k_minsnap(MinsnapArgs A) {
                     const int oi = __shfl_xor(ip, m, kLanes);
                     if (oi >= 0 && (ip < 0 || ow < worst || (ow == worst && oi < ip))) { worst = ow; ip = oi; }
                 }
-                if (ip < 0) break;
+                if (ip < 0) {
+                    if (polished < 2 && polish()) { ++polished; continue; }   // re-test the boxes at the polished point
+                    break;
+                }
                 if (lane == 0) { s_ip = ip; s_sip = worst; s_uq = 0.0; }
                 for (int i = lane; i < nf; i += kLanes) npv[i] = normal_of(ip, i);
                 __syncthreads();

@@ -19,39 +19,15 @@
 #include <set>
 
 #include "../../../include/vigo.h"
+#include "devbuf.h"
 
 using std::cout;
 using std::endl;
 
 namespace {
 
-// RAII device buffer; every HIP failure is reported to the caller as `false`
-struct DevBuf {
-    void* p = nullptr;
-    size_t n = 0;
-    bool keep = false;   // thread-lifetime staging buffers: left to the runtime's teardown, not freed after it
-    ~DevBuf() { if (p && !keep) (void)hipFree(p); }
-    bool upload(const void* src, size_t bytes) {
-        if (bytes > n) {
-            if (p) (void)hipFree(p);
-            p = nullptr;
-            n = 0;
-            if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return false;
-            n = bytes;
-        }
-        return bytes == 0 || hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
-    }
-    bool alloc(size_t bytes) {
-        if (bytes <= n && p) return true;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = 0;
-        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return false;
-        n = bytes;
-        return true;
-    }
-    bool download(void* dst, size_t bytes) const { return hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost) == hipSuccess; }
-};
+using vigo_host::DevBuf;
+using vigo_host::StagingBuf;
 
 // fn(i) for i in [0, n) on up to 16 host threads (planner-local work only)
 template <typename F>
@@ -67,10 +43,6 @@ void parallelFor(size_t n, F fn) {
     work();
     for (auto& t : pool) t.join();
 }
-
-struct StagingBuf : DevBuf {
-    StagingBuf() { keep = true; }
-};
 
 double wallSeconds() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();

@@ -1,0 +1,46 @@
+// devbuf.h — internal to the host facades: RAII device buffers for the staging copies around the C ABI calls.
+#ifndef VIGO_HOST_DEVBUF_H
+#define VIGO_HOST_DEVBUF_H
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+
+namespace vigo_host {
+
+// RAII device buffer; every HIP failure is reported to the caller as `false`
+struct DevBuf {
+    void* p = nullptr;
+    size_t n = 0;
+    bool keep = false;   // thread-lifetime staging buffers: left to the runtime's teardown, not freed after it
+    ~DevBuf() { if (p && !keep) (void)hipFree(p); }
+    bool upload(const void* src, size_t bytes) {
+        if (bytes > n) {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+            n = 0;
+            if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return false;
+            n = bytes;
+        }
+        return bytes == 0 || hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    bool alloc(size_t bytes) {
+        if (bytes <= n && p) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return false;
+        n = bytes;
+        return true;
+    }
+    bool download(void* dst, size_t bytes) const { return hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost) == hipSuccess; }
+};
+
+// thread-lifetime staging buffer (declare `static thread_local`): grows on demand, is reused by every later call
+// of the thread — hipMalloc/hipFree per planning round cost more than the round's kernels — and is left to the
+// runtime's teardown instead of being freed after it
+struct StagingBuf : DevBuf {
+    StagingBuf() { keep = true; }
+};
+
+}  // namespace vigo_host
+#endif  /* VIGO_HOST_DEVBUF_H */

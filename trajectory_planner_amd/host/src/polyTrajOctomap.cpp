@@ -10,6 +10,7 @@
 #include <iostream>
 
 #include "../../../include/vigo.h"
+#include "devbuf.h"
 
 using std::cout;
 using std::endl;
@@ -102,14 +103,11 @@ bool polyTrajOctomap::sweepPoints(const std::vector<pose>& pts, std::vector<uint
     if (!syncDevice()) return false;
     std::vector<double> xyz(pts.size() * 3);
     for (size_t i = 0; i < pts.size(); ++i) { xyz[3 * i] = pts[i].x; xyz[3 * i + 1] = pts[i].y; xyz[3 * i + 2] = pts[i].z; }
-    void *dP = nullptr, *dF = nullptr;
-    bool ok = hipMalloc(&dP, xyz.size() * 8) == hipSuccess && hipMalloc(&dF, pts.size()) == hipSuccess &&
-              hipMemcpy(dP, xyz.data(), xyz.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+    static thread_local vigo_host::StagingBuf dP, dF;      // reused by every sweep of this thread
+    bool ok = dP.upload(xyz.data(), xyz.size() * 8) && dF.alloc(pts.size());
     const double box[3] = {collisionBox_[0], collisionBox_[1], collisionBox_[2]};
-    ok = ok && vigo_box_collision_points(dev_, (int64_t)pts.size(), (const double*)dP, box, mapRes_, (uint8_t*)dF) == VIGO_OK;
-    ok = ok && hipDeviceSynchronize() == hipSuccess && hipMemcpy(flags.data(), dF, pts.size(), hipMemcpyDeviceToHost) == hipSuccess;
-    if (dP) (void)hipFree(dP);
-    if (dF) (void)hipFree(dF);
+    ok = ok && vigo_box_collision_points(dev_, (int64_t)pts.size(), (const double*)dP.p, box, mapRes_, (uint8_t*)dF.p) == VIGO_OK;
+    ok = ok && hipDeviceSynchronize() == hipSuccess && dF.download(flags.data(), pts.size());
     if (!ok && dev_) cout << "[Trajectory Planner INFO]: device box sweep failed: " << vigo_last_error(dev_) << endl;
     return ok;
 }
@@ -331,11 +329,10 @@ std::vector<bool> polyTrajOctomap::makePlanBatch(const std::vector<polyTrajOctom
         st[g].corridor.assign(K, p->initR_);
         st[g].t0 = nowSec();
     }
-    void *dWp = nullptr, *dCor = nullptr, *dCo = nullptr, *dKn = nullptr, *dSt = nullptr, *dPts = nullptr, *dFl = nullptr;
-    size_t ptsCap = 0;
+    static thread_local vigo_host::StagingBuf bWp, bCor, bCo, bKn, bSt, bPts, bFl;   // reused by every batch of this thread
     const size_t G = grp.size();
-    bool ok = hipMalloc(&dWp, G * W * 24) == hipSuccess && hipMalloc(&dCor, G * K * 8) == hipSuccess && hipMalloc(&dCo, G * K * 3 * D * 8) == hipSuccess &&
-              hipMalloc(&dKn, G * W * 8) == hipSuccess && hipMalloc(&dSt, G * 4) == hipSuccess;
+    bool ok = bWp.alloc(G * W * 24) && bCor.alloc(G * K * 8) && bCo.alloc(G * K * 3 * D * 8) && bKn.alloc(G * W * 8) && bSt.alloc(G * 4);
+    void *dWp = bWp.p, *dCor = bCor.p, *dCo = bCo.p, *dKn = bKn.p, *dSt = bSt.p, *dPts = nullptr, *dFl = nullptr;
     std::vector<double> hWp, hCor, hCo(G * K * 3 * D);
     std::vector<int32_t> hSt(G);
     while (ok) {
@@ -381,14 +378,10 @@ std::vector<bool> polyTrajOctomap::makePlanBatch(const std::vector<polyTrajOctom
             first[a + 1] = pts.size() / 3;
         }
         const size_t M = pts.size() / 3;
-        if (M > ptsCap) {
-            if (dPts) (void)hipFree(dPts);
-            if (dFl) (void)hipFree(dFl);
-            dPts = dFl = nullptr;
-            ok = hipMalloc(&dPts, M * 24) == hipSuccess && hipMalloc(&dFl, M) == hipSuccess;
-            ptsCap = ok ? M : 0;
-            if (!ok) break;
-        }
+        ok = bPts.alloc(M * 24) && bFl.alloc(M);
+        if (!ok) break;
+        dPts = bPts.p;
+        dFl = bFl.p;
         std::vector<uint8_t> flags(M, 1);
         const double box[3] = {lead->collisionBox_[0], lead->collisionBox_[1], lead->collisionBox_[2]};
         ok = hipMemcpy(dPts, pts.data(), M * 24, hipMemcpyHostToDevice) == hipSuccess &&
@@ -420,7 +413,6 @@ std::vector<bool> polyTrajOctomap::makePlanBatch(const std::vector<polyTrajOctom
             p->lastIterations_ = st[g].iters;
         }
     }
-    for (void* q : {dWp, dCor, dCo, dKn, dSt, dPts, dFl}) if (q) (void)hipFree(q);
     for (size_t g = 0; g < G; ++g) {
         polyTrajOctomap* p = ps[grp[g]];
         if (!p->findValidTraj_) { p->trajSolver_.reset(); p->pwlPlan(trajectories[grp[g]], p->delT_); }   // PO.cpp:459-467

@@ -63,6 +63,53 @@ static int dualActiveSet(int nf, const std::vector<double>& Hinv, const std::vec
     };
     const int maxIter = 50 * (nc + nf) + 100;
     int iter = 0;
+    int polished = 0;
+    // The primal point is carried along by increments t z.  On long corridors the working set walks from box
+    // to neighbouring box through dozens of nearly degenerate partial steps and the increments leave w up to
+    // 1e-5 (relative) off the face the working set defines — feasible, but measurably sub-optimal (found by
+    // tools/fuzz_minsnap.py against scipy's trust-constr).  Once nothing is violated any more, w and the
+    // multipliers are therefore recomputed from the working set itself: u = M^-1 (b_A + N H^-1 c),
+    // w = H^-1 (N'u - c); should that uncover a violated box, the loop resumes from the polished point.
+    auto polish = [&]() -> bool {
+        const int q = (int)act.size();
+        if (q == 0) return false;
+        std::vector<double> hc(nf), HNp((size_t)nf * q), Mp((size_t)q * q), un(q);
+        for (int i = 0; i < nf; ++i) {
+            double s = 0;
+            for (int j = 0; j < nf; ++j) s += Hinv[(size_t)i * nf + j] * c[j];
+            hc[i] = s;
+        }
+        for (int j = 0; j < q; ++j) {
+            const double* nj = &Acon[(size_t)act[j] * nf];
+            for (int i = 0; i < nf; ++i) {
+                double s = 0;
+                for (int k = 0; k < nf; ++k) s += Hinv[(size_t)i * nf + k] * nj[k];
+                HNp[(size_t)i * q + j] = s;
+            }
+        }
+        for (int a = 0; a < q; ++a) {
+            const double* na = &Acon[(size_t)act[a] * nf];
+            for (int b = 0; b <= a; ++b) {
+                double s = 0;
+                for (int i = 0; i < nf; ++i) s += na[i] * HNp[(size_t)i * q + b];
+                Mp[(size_t)a * q + b] = s;
+            }
+            double s = bcon[act[a]];
+            for (int i = 0; i < nf; ++i) s += na[i] * hc[i];
+            un[a] = s;
+        }
+        if (!cholesky(Mp, q)) return false;
+        cholSolve(Mp, q, un.data());
+        for (int a = 0; a < q; ++a)
+            if (!(un[a] >= 0.0)) return false;              // not the optimal working set after all: keep the carried point
+        for (int i = 0; i < nf; ++i) {
+            double s = -hc[i];
+            for (int a = 0; a < q; ++a) s += HNp[(size_t)i * q + a] * un[a];
+            w[i] = s;
+        }
+        u = un;
+        return true;
+    };
     for (;;) {
         int ip = -1;
         double worst = 0;
@@ -71,7 +118,10 @@ static int dualActiveSet(int nf, const std::vector<double>& Hinv, const std::vec
             const double s = slack(k), tol = 1e-9 * (1.0 + std::fabs(bcon[k]));
             if (s < -tol && s < worst) { worst = s; ip = k; }
         }
-        if (ip < 0) return iter;
+        if (ip < 0) {
+            if (polished < 2 && polish()) { ++polished; continue; }   // re-test the boxes at the polished point
+            return iter;
+        }
         const double* np = &Acon[(size_t)ip * nf];
         double uq = 0.0, sip = worst;
         for (;;) {
@@ -146,142 +196,218 @@ static int dualActiveSet(int nf, const std::vector<double>& Hinv, const std::vec
 // min 1/2 x'Px + q'x  s.t.  l <= Ax <= u.  Rows with l == u are eliminated with an orthonormal
 // null-space basis (Householder QR of A_eq'): for the min-snap problem that leaves 2 free
 // coefficients per segment, a tiny strictly convex QP in which only the corridor boxes remain —
-// solved exactly by the dual active-set method above.  Returns iterations >= 0, -1 numerical
-// failure (rank-deficient equalities), -2 infeasible.
-int solveDenseQP(int n, int m, const std::vector<double>& P, const std::vector<double>& q, const std::vector<double>& A,
-                 const std::vector<double>& l, const std::vector<double>& u, std::vector<double>& x) {
+// solved exactly by the dual active-set method above.
+//
+// The three axes of a path share P, A and the split of the rows into equalities and boxes; only the
+// right-hand sides differ.  Everything that depends on the matrices alone — row scaling, the QR, Z'PZ and
+// its inverse, the box normals in the reduced space — is computed once (factor) and reused per axis (solve).
+namespace {
+struct ReducedQP {
+    int n = 0, m = 0, me = 0, nf = 0;
     std::vector<int> eqRows, inRows;
-    for (int r = 0; r < m; ++r) {
-        if (l[r] > u[r]) return -2;
-        if (l[r] == u[r]) eqRows.push_back(r);
-        else if (l[r] > -INFINITY || u[r] < INFINITY) inRows.push_back(r);
-    }
-    const int me = (int)eqRows.size(), mi = (int)inRows.size();
-    if (me > n) return -1;
-    // Mt = A_eq' (n x me), rows scaled to unit infinity norm first (continuity rows carry dt^4)
-    std::vector<double> Mt((size_t)n * me), beq(me);
-    for (int j = 0; j < me; ++j) {
-        const double* a = &A[(size_t)eqRows[j] * n];
-        double mx = 0;
-        for (int i = 0; i < n; ++i) mx = std::max(mx, std::fabs(a[i]));
-        if (!(mx > 0)) return -1;
-        for (int i = 0; i < n; ++i) Mt[(size_t)i * me + j] = a[i] / mx;
-        beq[j] = l[eqRows[j]] / mx;
-    }
-    // Householder QR: Mt = Q R; Q accumulated explicitly (n x n)
-    std::vector<double> Q((size_t)n * n, 0.0), v(n);
-    for (int i = 0; i < n; ++i) Q[(size_t)i * n + i] = 1.0;
-    for (int j = 0; j < me; ++j) {
-        double nrm = 0;
-        for (int i = j; i < n; ++i) nrm += Mt[(size_t)i * me + j] * Mt[(size_t)i * me + j];
-        nrm = std::sqrt(nrm);
-        if (!(nrm > 1e-10)) return -1;                          // dependent equality rows
-        const double alpha = Mt[(size_t)j * me + j] > 0 ? -nrm : nrm;
-        for (int i = 0; i < n; ++i) v[i] = i < j ? 0.0 : Mt[(size_t)i * me + j];
-        v[j] -= alpha;
-        double vv = 0;
-        for (int i = j; i < n; ++i) vv += v[i] * v[i];
-        if (vv > 0) {
-            for (int c = j; c < me; ++c) {                      // Mt <- (I - 2vv'/v'v) Mt
-                double s = 0;
-                for (int i = j; i < n; ++i) s += v[i] * Mt[(size_t)i * me + c];
-                s *= 2.0 / vv;
-                for (int i = j; i < n; ++i) Mt[(size_t)i * me + c] -= s * v[i];
-            }
-            for (int rr = 0; rr < n; ++rr) {                    // Q <- Q (I - 2vv'/v'v)
-                double s = 0;
-                for (int i = j; i < n; ++i) s += Q[(size_t)rr * n + i] * v[i];
-                s *= 2.0 / vv;
-                for (int i = j; i < n; ++i) Q[(size_t)rr * n + i] -= s * v[i];
+    std::vector<double> mx;        // infinity norm of each equality row (the rows are scaled by it)
+    std::vector<double> Rt;        // n x me: the R factor of A_eq' = Q R in its upper triangle
+    std::vector<double> Q;         // n x n orthogonal; Z = Q[:, me:]
+    std::vector<double> PZ, Hinv;  // n x nf, nf x nf
+    std::vector<double> AZ;        // |inRows| x nf: box rows in the reduced space
+    std::vector<double> Pm, Am;    // the matrices this factorisation belongs to (own copies: the cache key)
+    const std::vector<double>* P = nullptr;
+    const std::vector<double>* A = nullptr;
+
+    double Zc(int i, int k) const { return Q[(size_t)i * n + me + k]; }
+
+    // returns 0, or -1 on rank-deficient equalities / a reduced Hessian that is not positive definite
+    int factor(int n_, int m_, const std::vector<double>& P_, const std::vector<double>& A_, const std::vector<double>& l,
+               const std::vector<double>& u) {
+        n = n_; m = m_;
+        Pm = P_; Am = A_;
+        P = &Pm; A = &Am;
+        eqRows.clear(); inRows.clear();
+        for (int r = 0; r < m; ++r) {
+            if (l[r] == u[r]) eqRows.push_back(r);
+            else if (l[r] > -INFINITY || u[r] < INFINITY) inRows.push_back(r);
+        }
+        me = (int)eqRows.size();
+        if (me > n) return -1;
+        nf = n - me;
+        // Rt = A_eq' (n x me), rows scaled to unit infinity norm first (continuity rows carry dt^4)
+        Rt.assign((size_t)n * me, 0.0);
+        mx.assign(me, 0.0);
+        for (int j = 0; j < me; ++j) {
+            const double* a = &A_[(size_t)eqRows[j] * n];
+            double mj = 0;
+            for (int i = 0; i < n; ++i) mj = std::max(mj, std::fabs(a[i]));
+            if (!(mj > 0)) return -1;
+            for (int i = 0; i < n; ++i) Rt[(size_t)i * me + j] = a[i] / mj;
+            mx[j] = mj;
+        }
+        // Householder QR: Rt = Q R; Q accumulated explicitly (n x n)
+        Q.assign((size_t)n * n, 0.0);
+        std::vector<double> v(n);
+        for (int i = 0; i < n; ++i) Q[(size_t)i * n + i] = 1.0;
+        for (int j = 0; j < me; ++j) {
+            double nrm = 0;
+            for (int i = j; i < n; ++i) nrm += Rt[(size_t)i * me + j] * Rt[(size_t)i * me + j];
+            nrm = std::sqrt(nrm);
+            if (!(nrm > 1e-10)) return -1;                          // dependent equality rows
+            const double alpha = Rt[(size_t)j * me + j] > 0 ? -nrm : nrm;
+            for (int i = 0; i < n; ++i) v[i] = i < j ? 0.0 : Rt[(size_t)i * me + j];
+            v[j] -= alpha;
+            double vv = 0;
+            for (int i = j; i < n; ++i) vv += v[i] * v[i];
+            if (vv > 0) {
+                for (int c = j; c < me; ++c) {                      // Rt <- (I - 2vv'/v'v) Rt
+                    double sc = 0;
+                    for (int i = j; i < n; ++i) sc += v[i] * Rt[(size_t)i * me + c];
+                    sc *= 2.0 / vv;
+                    for (int i = j; i < n; ++i) Rt[(size_t)i * me + c] -= sc * v[i];
+                }
+                for (int rr = 0; rr < n; ++rr) {                    // Q <- Q (I - 2vv'/v'v)
+                    double sc = 0;
+                    for (int i = j; i < n; ++i) sc += Q[(size_t)rr * n + i] * v[i];
+                    sc *= 2.0 / vv;
+                    for (int i = j; i < n; ++i) Q[(size_t)rr * n + i] -= sc * v[i];
+                }
             }
         }
-    }
-    // particular solution x0 = Y R^-T beq  (A_eq = R'Q' => (Q'x)[:me] = R^-T beq)
-    std::vector<double> y(me), x0(n, 0.0);
-    for (int i = 0; i < me; ++i) {
-        double s = beq[i];
-        for (int k = 0; k < i; ++k) s -= Mt[(size_t)k * me + i] * y[k];
-        y[i] = s / Mt[(size_t)i * me + i];
-    }
-    for (int i = 0; i < n; ++i) {
-        double s = 0;
-        for (int k = 0; k < me; ++k) s += Q[(size_t)i * n + k] * y[k];
-        x0[i] = s;
-    }
-    const int nf = n - me;
-    x = x0;
-    if (nf == 0) {
-        for (int r : inRows) {
-            double s = 0;
-            for (int i = 0; i < n; ++i) s += A[(size_t)r * n + i] * x[i];
-            if (s < l[r] - 1e-9 || s > u[r] + 1e-9) return -2;
+        if (nf == 0) return 0;
+        // reduced Hessian H = Z'PZ and its inverse
+        PZ.assign((size_t)n * nf, 0.0);
+        for (int i = 0; i < n; ++i)
+            for (int jj = 0; jj < n; ++jj) {
+                const double pij = P_[(size_t)i * n + jj];
+                if (pij == 0.0) continue;
+                for (int k = 0; k < nf; ++k) PZ[(size_t)i * nf + k] += pij * Zc(jj, k);
+            }
+        std::vector<double> H((size_t)nf * nf, 0.0);
+        for (int a = 0; a < nf; ++a)
+            for (int b = 0; b < nf; ++b) {
+                double sc = 0;
+                for (int i = 0; i < n; ++i) sc += Zc(i, a) * PZ[(size_t)i * nf + b];
+                H[(size_t)a * nf + b] = sc;
+            }
+        for (int a = 0; a < nf; ++a)
+            for (int b = 0; b < a; ++b) H[(size_t)a * nf + b] = H[(size_t)b * nf + a] = 0.5 * (H[(size_t)a * nf + b] + H[(size_t)b * nf + a]);
+        if (!cholesky(H, nf)) return -1;
+        Hinv.assign((size_t)nf * nf, 0.0);
+        std::vector<double> col(nf);
+        for (int k = 0; k < nf; ++k) {
+            std::fill(col.begin(), col.end(), 0.0);
+            col[k] = 1.0;
+            cholSolve(H, nf, col.data());
+            for (int i = 0; i < nf; ++i) Hinv[(size_t)i * nf + k] = col[i];
+        }
+        // box rows in the reduced space: A_r Z
+        AZ.assign(inRows.size() * (size_t)nf, 0.0);
+        for (size_t ri = 0; ri < inRows.size(); ++ri) {
+            const double* a = &A_[(size_t)inRows[ri] * n];
+            for (int i = 0; i < n; ++i) {
+                if (a[i] == 0.0) continue;
+                for (int k = 0; k < nf; ++k) AZ[ri * nf + k] += a[i] * Zc(i, k);
+            }
         }
         return 0;
     }
-    // reduced problem in w: x = x0 + Z w, Z = Q[:, me:]
-    auto Zc = [&](int i, int k) { return Q[(size_t)i * n + me + k]; };
-    std::vector<double> PZ((size_t)n * nf, 0.0), H((size_t)nf * nf, 0.0), c(nf, 0.0), g(n, 0.0);
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-            const double pij = P[(size_t)i * n + j];
-            if (pij == 0.0) continue;
-            for (int k = 0; k < nf; ++k) PZ[(size_t)i * nf + k] += pij * Zc(j, k);
-            g[i] += pij * x0[j];
-        }
-    for (int i = 0; i < n; ++i) g[i] += q[i];
-    for (int a = 0; a < nf; ++a) {
-        for (int b = 0; b < nf; ++b) {
-            double s = 0;
-            for (int i = 0; i < n; ++i) s += Zc(i, a) * PZ[(size_t)i * nf + b];
-            H[(size_t)a * nf + b] = s;
-        }
-        double s = 0;
-        for (int i = 0; i < n; ++i) s += Zc(i, a) * g[i];
-        c[a] = s;
+
+    // made for exactly these matrices (bitwise) — then only the row split remains to be compared
+    bool sameMatrices(int n_, int m_, const std::vector<double>& P_, const std::vector<double>& A_) const {
+        return n_ == n && m_ == m && P_ == Pm && A_ == Am;
     }
-    for (int a = 0; a < nf; ++a)
-        for (int b = 0; b < a; ++b) H[(size_t)a * nf + b] = H[(size_t)b * nf + a] = 0.5 * (H[(size_t)a * nf + b] + H[(size_t)b * nf + a]);
-    std::vector<double> Lh(H);
-    if (!cholesky(Lh, nf)) return -1;
-    std::vector<double> Hinv((size_t)nf * nf, 0.0), col(nf);
-    for (int k = 0; k < nf; ++k) {
-        std::fill(col.begin(), col.end(), 0.0);
-        col[k] = 1.0;
-        cholSolve(Lh, nf, col.data());
-        for (int i = 0; i < nf; ++i) Hinv[(size_t)i * nf + k] = col[i];
+
+    // the row split of (l, u) is the one this factorisation was made for
+    bool sameSplit(const std::vector<double>& l, const std::vector<double>& u) const {
+        size_t e = 0, q = 0;
+        for (int r = 0; r < m; ++r) {
+            if (l[r] == u[r]) { if (e >= eqRows.size() || eqRows[e++] != r) return false; }
+            else if (l[r] > -INFINITY || u[r] < INFINITY) { if (q >= inRows.size() || inRows[q++] != r) return false; }
+        }
+        return e == eqRows.size() && q == inRows.size();
     }
-    // inequality rows in w: lo <= (A_r Z) w + A_r x0 <= hi, as a'w >= b pairs
-    std::vector<double> Acon, bcon;
-    for (int r : inRows) {
-        std::vector<double> az(nf, 0.0);
-        double d0 = 0;
+
+    // iterations >= 0, -1 numerical failure, -2 infeasible
+    int solve(const std::vector<double>& q, const std::vector<double>& l, const std::vector<double>& u, std::vector<double>& x) const {
+        for (int r = 0; r < m; ++r)
+            if (l[r] > u[r]) return -2;
+        // particular solution x0 = Y R^-T beq  (A_eq = R'Q' => (Q'x)[:me] = R^-T beq)
+        std::vector<double> y(me), x0(n, 0.0);
+        for (int i = 0; i < me; ++i) {
+            double sc = l[eqRows[i]] / mx[i];
+            for (int k = 0; k < i; ++k) sc -= Rt[(size_t)k * me + i] * y[k];
+            y[i] = sc / Rt[(size_t)i * me + i];
+        }
         for (int i = 0; i < n; ++i) {
-            const double ai = A[(size_t)r * n + i];
-            if (ai == 0.0) continue;
-            d0 += ai * x0[i];
-            for (int k = 0; k < nf; ++k) az[k] += ai * Zc(i, k);
+            double sc = 0;
+            for (int k = 0; k < me; ++k) sc += Q[(size_t)i * n + k] * y[k];
+            x0[i] = sc;
         }
-        if (l[r] > -INFINITY) { Acon.insert(Acon.end(), az.begin(), az.end()); bcon.push_back(l[r] - d0); }
-        if (u[r] < INFINITY) { for (double& t : az) t = -t; Acon.insert(Acon.end(), az.begin(), az.end()); bcon.push_back(d0 - u[r]); }
+        x = x0;
+        if (nf == 0) {
+            for (int r : inRows) {
+                double sc = 0;
+                for (int i = 0; i < n; ++i) sc += (*A)[(size_t)r * n + i] * x[i];
+                if (sc < l[r] - 1e-9 || sc > u[r] + 1e-9) return -2;
+            }
+            return 0;
+        }
+        // reduced gradient c = Z'(P x0 + q)
+        std::vector<double> g(n, 0.0), c(nf, 0.0);
+        for (int i = 0; i < n; ++i) {
+            double sc = q[i];
+            for (int jj = 0; jj < n; ++jj) {
+                const double pij = (*P)[(size_t)i * n + jj];
+                if (pij != 0.0) sc += pij * x0[jj];
+            }
+            g[i] = sc;
+        }
+        for (int a = 0; a < nf; ++a) {
+            double sc = 0;
+            for (int i = 0; i < n; ++i) sc += Zc(i, a) * g[i];
+            c[a] = sc;
+        }
+        // inequality rows in w: lo <= (A_r Z) w + A_r x0 <= hi, as a'w >= b pairs
+        std::vector<double> Acon, bcon;
+        Acon.reserve(2 * AZ.size());
+        for (size_t ri = 0; ri < inRows.size(); ++ri) {
+            const int r = inRows[ri];
+            const double* a = &(*A)[(size_t)r * n];
+            double d0 = 0;
+            for (int i = 0; i < n; ++i)
+                if (a[i] != 0.0) d0 += a[i] * x0[i];
+            const double* az = &AZ[ri * nf];
+            if (l[r] > -INFINITY) { Acon.insert(Acon.end(), az, az + nf); bcon.push_back(l[r] - d0); }
+            if (u[r] < INFINITY) { for (int k = 0; k < nf; ++k) Acon.push_back(-az[k]); bcon.push_back(d0 - u[r]); }
+        }
+        std::vector<double> w;
+        const int it = dualActiveSet(nf, Hinv, c, (int)bcon.size(), Acon, bcon, w);
+        if (it < 0) return it;
+        // The active-set loop only tests constraints outside its working set.  On an infeasible corridor
+        // rounding can hide the vanishing step direction (z'n ~ 1e-11 n'H^-1 n) and let it "finish" on an
+        // ill-conditioned working set: every box is verified at the end, a violation means infeasible.
+        for (size_t k = 0; k < bcon.size(); ++k) {
+            double sl = -bcon[k];
+            for (int i = 0; i < nf; ++i) sl += Acon[k * nf + i] * w[i];
+            if (sl < -1e-7 * (1.0 + std::fabs(bcon[k]))) return -2;
+        }
+        for (int i = 0; i < n; ++i) {
+            double sc = 0;
+            for (int k = 0; k < nf; ++k) sc += Zc(i, k) * w[k];
+            x[i] = x0[i] + sc;
+        }
+        return it;
     }
-    std::vector<double> w;
-    const int it = dualActiveSet(nf, Hinv, c, (int)bcon.size(), Acon, bcon, w);
-    if (it < 0) return it;
-    // The active-set loop only tests constraints outside its working set.  On an infeasible corridor
-    // rounding can hide the vanishing step direction (z'n ~ 1e-11 n'H^-1 n) and let it "finish" on an
-    // ill-conditioned working set: every box is verified at the end, a violation means infeasible.
-    for (size_t k = 0; k < bcon.size(); ++k) {
-        double sl = -bcon[k];
-        for (int i = 0; i < nf; ++i) sl += Acon[k * nf + i] * w[i];
-        if (sl < -1e-7 * (1.0 + std::fabs(bcon[k]))) return -2;
-    }
-    for (int i = 0; i < n; ++i) {
-        double s = 0;
-        for (int k = 0; k < nf; ++k) s += Zc(i, k) * w[k];
-        x[i] = x0[i] + s;
-    }
-    (void)mi;
-    return it;
+};
+}  // namespace
+
+// one problem, factor + solve.  Returns iterations >= 0, -1 numerical failure (rank-deficient equalities),
+// -2 infeasible.
+int solveDenseQP(int n, int m, const std::vector<double>& P, const std::vector<double>& q, const std::vector<double>& A,
+                 const std::vector<double>& l, const std::vector<double>& u, std::vector<double>& x) {
+    for (int r = 0; r < m; ++r)
+        if (l[r] > u[r]) return -2;
+    ReducedQP qp;
+    const int rc = qp.factor(n, m, P, A, l, u);
+    if (rc < 0) return rc;
+    return qp.solve(q, l, u, x);
 }
 
 // ---- the min-snap problem -----------------------------------------------------------------
@@ -454,9 +580,18 @@ bool polyTrajSolver::solve() {
     constructBound(l, u);
     std::vector<double>* sol[3] = {&xSol_, &ySol_, &zSol_};
     bool ok = true;
+    // the three axes share the matrices and the equality/box split of the rows: one factorisation — which
+    // also survives from call to call while the path and the corridor rows stay the same (the corridor loop
+    // only shrinks radii, i.e. changes l and u): kept per host thread, keyed by the matrices themselves
+    static thread_local ReducedQP qp;
+    static thread_local int frcKept = -1;
+    int frc;
+    if (frcKept == 0 && qp.sameMatrices(paramDim_, constraintNum_, P, A) && qp.sameSplit(l[0], u[0])) frc = 0;
+    else frc = frcKept = qp.factor(paramDim_, constraintNum_, P, A, l[0], u[0]);
     for (int a = 0; a < 3; ++a) {
         std::vector<double> x;
-        const int it = solveDenseQP(paramDim_, constraintNum_, P, q, A, l[a], u[a], x);
+        int it = frc;
+        if (frc == 0) it = qp.sameSplit(l[a], u[a]) ? qp.solve(q, l[a], u[a], x) : solveDenseQP(paramDim_, constraintNum_, P, q, A, l[a], u[a], x);
         if (it < 0) { ok = false; continue; }   // infeasible corridor / degenerate path: keep the stale solution, like the reference
         // PS.cpp:874-878: back to un-normalised local time
         for (size_t s = 0; s + 1 < path_.size(); ++s)
