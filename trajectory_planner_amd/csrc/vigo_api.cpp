@@ -387,7 +387,6 @@ int vigo_bspline_fit(vigo_handle_t h, int B, int K, double ts, const double* poi
         const size_t need = vigo::fit_pinv_doubles(K);
         if (need > h->fit_capacity) {
             if (h->fit_pinvT) (void)hipFree(h->fit_pinvT);
-    if (h->times_dev) (void)hipFree(h->times_dev);
             h->fit_pinvT = nullptr;
             h->fit_capacity = 0;
             h->fit_K = 0;
