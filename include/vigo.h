@@ -15,7 +15,10 @@
  *   - return value: 0 = VIGO_OK, negative = vigo_status_t error.  Per-trajectory solver
  *     results use the reference's own L-BFGS codes (LB:20-80) in `out_status`.
  *   - a handle owns its device buffers and HIP stream binding; calls on one handle are
- *     serialized by the caller; there is no global state.
+ *     serialized by the caller; there is no global state.  A handle belongs to the device it was
+ *     created on: that device must be the calling thread's current HIP device during every call
+ *     (one process per GPU, or hipSetDevice first) — launches go to the bound stream / the current
+ *     device's default stream.
  *   - all floating point arrays are fp64 (the reference's arithmetic, BT.h:22) unless the
  *     name says f32.
  *

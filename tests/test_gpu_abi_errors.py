@@ -130,6 +130,10 @@ def test_bad_arguments_return_codes_and_keep_the_handle_usable(raw):
     assert L.vigo_corridor_check(h, 1, 99, dptr(d), dptr(i32), dptr(d), box, 0.1, dptr(o), NULL, NULL) < 0
     assert L.vigo_corridor_check(h, 1, 7, dptr(d), dptr(i32), dptr(d), box, 0.0, dptr(o), NULL, NULL) < 0
     assert L.vigo_corridor_check(h, 1, 7, dptr(d), dptr(i32), dptr(d), None, 0.1, dptr(o), NULL, NULL) < 0
+    for bad_box in ((float("nan"), 0.4, 0.2), (float("inf"), 0.4, 0.2), (1e9, 1e9, 1e9), (100.0, 100.0, 100.0)):
+        bb = (C.c_double * 3)(*bad_box)                      # an unbounded (or absurd) lattice per pose is refused
+        assert L.vigo_corridor_check(h, 1, 7, dptr(d), dptr(i32), dptr(d), bb, 0.1, dptr(o), NULL, NULL) < 0
+        assert L.vigo_box_collision_points(h, 4, dptr(d), bb, 0.1, dptr(o)) < 0
     assert L.vigo_box_collision_points(h, 4, NULL, box, 0.1, dptr(o)) < 0
     assert L.vigo_box_collision_points(h, 4, dptr(d), box, -0.1, dptr(o)) < 0
     # ESDF

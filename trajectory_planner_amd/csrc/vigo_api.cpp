@@ -109,6 +109,28 @@ int upload_sample_times(vigo_handle_t h, double tmax, double dt, int* out_T, con
     return VIGO_OK;
 }
 
+// The box sweep visits (box / map_res + 1) lattice points per axis for every pose: a finite box and a bounded
+// lattice, or the sweep is an unbounded device loop (the cfg box is 0.4 x 0.4 x 0.2 at 0.2: 3 x 3 x 2 points).
+// Negative extents are the reference's "no lattice point at all" and stay allowed.
+bool sweep_box_ok(const double box[3], double map_res) {
+    double pts = 1.0;
+    for (int a = 0; a < 3; ++a) {
+        if (!(fabs(box[a]) < 1e9)) return false;
+        const double n = box[a] > 0 ? floor(box[a] / map_res) + 1.0 : 1.0;
+        if (!(n <= 256.0)) return false;
+        pts *= n;
+    }
+    return pts <= 32768.0;
+}
+
+// a finite origin and a finite positive resolution (the key offsets below are integer conversions of origin / res)
+bool geometry_ok(const double origin[3], double res) {
+    if (!(res > 0.0) || !(res < 1e12)) return false;
+    for (int a = 0; a < 3; ++a)
+        if (!(fabs(origin[a]) < 1e12) || !(fabs(origin[a] / res) < 2e9)) return false;
+    return true;
+}
+
 void fill_grid_view(vigo_handle_t h, int nx, int ny, int nz, const double origin[3], double res) {
     GridView& g = h->grid;
     g.planes = h->grid_planes;
@@ -282,7 +304,7 @@ int vigo_inflate_grid(vigo_handle_t h, int nx, int ny, int nz, uint8_t* voxels_d
 }
 
 int vigo_set_grid(vigo_handle_t h, int nx, int ny, int nz, const double origin[3], double res, const uint8_t* voxels_dev) {
-    if (!h || !voxels_dev || !origin || nx <= 0 || ny <= 0 || nz <= 0 || !(res > 0)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_grid: bad argument");
+    if (!h || !voxels_dev || !origin || nx <= 0 || ny <= 0 || nz <= 0 || !geometry_ok(origin, res)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_grid: bad argument");
     int rc = ensure_grid_storage(h, nx, ny, nz);
     if (rc) return rc;
     VIGO_HIP(h, (hipError_t)vigo::launch_pack_grid(h->stream, nx, ny, nz, voxels_dev, h->grid_planes));
@@ -291,7 +313,7 @@ int vigo_set_grid(vigo_handle_t h, int nx, int ny, int nz, const double origin[3
 }
 
 int vigo_set_grid_host(vigo_handle_t h, int nx, int ny, int nz, const double origin[3], double res, const uint8_t* voxels_host) {
-    if (!h || !voxels_host || !origin || nx <= 0 || ny <= 0 || nz <= 0 || !(res > 0)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_grid_host: bad argument");
+    if (!h || !voxels_host || !origin || nx <= 0 || ny <= 0 || nz <= 0 || !geometry_ok(origin, res)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_grid_host: bad argument");
     size_t bytes = (size_t)nx * ny * nz;
     int rc = ensure_scratch(h, bytes);
     if (rc) return rc;
@@ -303,7 +325,7 @@ int vigo_set_grid_host(vigo_handle_t h, int nx, int ny, int nz, const double ori
 }
 
 int vigo_set_grid_packed(vigo_handle_t h, int nx, int ny, int nz, const double origin[3], double res, const uint32_t* packed_dev) {
-    if (!h || !packed_dev || !origin || nx <= 0 || ny <= 0 || nz <= 0 || !(res > 0)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_grid_packed: bad argument");
+    if (!h || !packed_dev || !origin || nx <= 0 || ny <= 0 || nz <= 0 || !geometry_ok(origin, res)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_grid_packed: bad argument");
     int rc = ensure_grid_storage(h, nx, ny, nz);
     if (rc) return rc;
     VIGO_HIP(h, hipMemcpyAsync(h->grid_planes, packed_dev, vigo_grid_packed_bytes(nx, ny, nz), hipMemcpyDeviceToDevice, h->stream));
@@ -480,6 +502,7 @@ int vigo_corridor_check(vigo_handle_t h, int S, int deg, const double* coeffs, c
     if (!h) return VIGO_ERR_INVALID_ARG;
     if (S < 0 || deg < 0 || deg > 15 || !box || !(map_res > 0) || (S > 0 && (!coeffs || !n_samp || !delT || !out_flag)))
         return fail(h, VIGO_ERR_INVALID_ARG, "vigo_corridor_check: bad argument");
+    if (!sweep_box_ok(box, map_res)) return fail(h, VIGO_ERR_UNSUPPORTED, "vigo_corridor_check: collision box not finite or more than 32768 lattice points per pose");
     if (!h->has_grid) return fail(h, VIGO_ERR_NO_GRID, "vigo_corridor_check before vigo_set_grid");
     for (int a = 0; a < 3; ++a) {
         double q = h->grid.origin[a] / h->grid.res;
@@ -494,6 +517,7 @@ int vigo_corridor_check(vigo_handle_t h, int S, int deg, const double* coeffs, c
 int vigo_box_collision_points(vigo_handle_t h, int64_t M, const double* pts, const double box[3], double map_res, uint8_t* out) {
     if (!h) return VIGO_ERR_INVALID_ARG;
     if (M < 0 || !box || !(map_res > 0) || (M > 0 && (!pts || !out))) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_box_collision_points: bad argument");
+    if (!sweep_box_ok(box, map_res)) return fail(h, VIGO_ERR_UNSUPPORTED, "vigo_box_collision_points: collision box not finite or more than 32768 lattice points per pose");
     if (!h->has_grid) return fail(h, VIGO_ERR_NO_GRID, "vigo_box_collision_points before vigo_set_grid");
     for (int a = 0; a < 3; ++a) {
         double q = h->grid.origin[a] / h->grid.res;
@@ -507,7 +531,7 @@ int vigo_box_collision_points(vigo_handle_t h, int64_t M, const double* pts, con
 /* ---- ESDF ----------------------------------------------------------------------------------- */
 
 int vigo_set_esdf(vigo_handle_t h, int nx, int ny, int nz, const double origin[3], double res, const float* dist_dev) {
-    if (!h || !dist_dev || !origin || nx < 2 || ny < 2 || nz < 2 || !(res > 0)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_esdf: bad argument");
+    if (!h || !dist_dev || !origin || nx < 2 || ny < 2 || nz < 2 || !geometry_ok(origin, res)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_esdf: bad argument");
     if ((long long)nx * ny * nz > (1LL << 33)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_esdf: lattice too large");
     size_t bytes = vigo::esdf_bricked_floats(nx, ny, nz) * sizeof(float);
     if (bytes > h->esdf_capacity) {
