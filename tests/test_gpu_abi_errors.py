@@ -103,6 +103,12 @@ def test_bad_arguments_return_codes_and_keep_the_handle_usable(raw):
     torch.cuda.synchronize()
     i32.zero_()
     assert L.vigo_optimize(h, 0, 32, NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL) == 0   # empty batch
+    from trajectory_planner_amd.vigo import default_params
+    for field, val in (("ts_ctrl", float("inf")), ("ts", float("inf")), ("ts_ctrl", float("nan")), ("max_linesearch", 2**31 - 1),
+                       ("max_iterations", 2**31 - 1), ("mem_size", 0), ("mem_size", 17), ("past", 1), ("pred_horizon", 0.0)):
+        Pb = default_params()
+        setattr(Pb, field, val)
+        assert L.vigo_set_params(h, C.byref(Pb)) < 0, field      # refused: the handle keeps its previous parameters
     assert L.vigo_set_precision(h, 17) < 0
     assert L.vigo_set_params(h, None) < 0
     # spline / gates

@@ -246,7 +246,11 @@ int vigo_set_params(vigo_handle_t h, const vigo_params_t* p) {
     // lbfgs.hpp treats max_iterations == 0 as "until convergence or error" (LB:127-131); a device kernel
     // must have a bound every wave reaches, so the unbounded setting is refused (the reference runs 200)
     if (p->max_iterations == 0) return fail(h, VIGO_ERR_UNSUPPORTED, "max_iterations == 0 (unbounded) is not supported on the device");
-    if (!(p->ts > 0) || !(p->ts_ctrl > 0)) return fail(h, VIGO_ERR_INVALID_ARG, "ts and ts_ctrl must be > 0");
+    // (finite: an infinite knot spacing makes the span search of the spline evaluation spin on NaN knots)
+    if (!(p->ts > 0) || !(p->ts_ctrl > 0) || !(p->ts < 1e9) || !(p->ts_ctrl < 1e9)) return fail(h, VIGO_ERR_INVALID_ARG, "ts and ts_ctrl must be finite and > 0");
+    // every device loop needs a bound a wave reaches in reasonable time (the reference runs 200 / 40)
+    if (p->max_iterations > 1000000 || p->max_linesearch > 100000)
+        return fail(h, VIGO_ERR_UNSUPPORTED, "max_iterations > 1e6 or max_linesearch > 1e5");
     // predictionNum = int(predHorizon / ts) divides n in the dynamic-obstacle term (BT.cpp:1006, :1020): 0 is a
     // division by zero in the reference; a huge value is an unbounded device loop
     if (!(p->pred_horizon / p->ts >= 1.0) || !(p->pred_horizon / p->ts <= 100000.0))
