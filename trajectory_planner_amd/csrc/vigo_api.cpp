@@ -260,6 +260,7 @@ int vigo_set_params(vigo_handle_t h, const vigo_params_t* p) {
         p->f_dec_coeff < 0. || p->s_curv_coeff <= p->f_dec_coeff || 1. <= p->s_curv_coeff ||
         p->xtol < 0. || p->max_linesearch <= 0 || p->max_iterations < 0)
         return fail(h, VIGO_ERR_INVALID_ARG, "invalid L-BFGS parameter (see lbfgs.hpp:1060-1104)");
+    if (memcmp(&h->params, p, sizeof(*p)) == 0) return VIGO_OK;   // unchanged (callers re-send them per round): no copy, no sync
     h->params = *p;
     h->dc = vigo::make_dev_const(h->params);
     // blocking copy: every launch issued after this call sees the new constants, whatever its stream
