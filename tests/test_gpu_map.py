@@ -225,3 +225,19 @@ def test_stale_hip_error_of_another_library_is_not_reported(vigo_handle):
                  lambda: v.query_points(to_dev(np.zeros((5, 3)), v.device), 0)):
         assert hip.hipFree(C.c_void_p(0x1234)) != 0          # leaves hipErrorInvalidValue behind
         call()                                                # must not raise
+
+
+def test_bspline_eval_beyond_the_grid_y_limit(vigo_handle):
+    """more trajectories than gridDim.y allows in one launch (65535): sliced launches, same values"""
+    v = vigo_handle
+    rng = np.random.default_rng(4)
+    B, N = 70001, 8
+    ctrl = to_dev(rng.normal(size=(B, N, 3)), v.device)
+    times = to_dev(np.array([0.0, 0.13, 0.5, 0.99]), v.device)
+    out = v.bspline_eval(ctrl, times, 0)
+    ref = v.bspline_eval(ctrl[65000:], times, 0)
+    assert torch.equal(out[65000:], ref) and bool(torch.isfinite(out).all())
+    one = np.zeros(3)
+    c = np.ascontiguousarray(ctrl[70000].cpu().numpy())
+    ol.oracle().vgo_traj_eval(N, ol._d(c), default_params().ts_ctrl, 0, 0.5, ol._d(one))
+    assert np.array_equal(out[70000, 2].cpu().numpy(), one)

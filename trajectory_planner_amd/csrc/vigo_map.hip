@@ -267,8 +267,12 @@ int launch_bspline_eval(hipStream_t s, int B, int N, const double* ctrl, double 
                         int T, const double* times, double* out) {
     if (B <= 0 || T <= 0) return hipSuccess;
     const int block = 64;
-    hipLaunchKernelGGL(k_bspline_eval, dim3((T + block - 1) / block, B), dim3(block), 0, s, B, N, ctrl, ts_ctrl,
-                       deriv, T, times, out);
+    // gridDim.y is limited to 65535: larger batches go out in slices of that many trajectories
+    for (int b0 = 0; b0 < B; b0 += 65535) {
+        const int nb = (B - b0) < 65535 ? (B - b0) : 65535;
+        hipLaunchKernelGGL(k_bspline_eval, dim3((T + block - 1) / block, nb), dim3(block), 0, s, nb, N, ctrl + (size_t)b0 * N * 3,
+                           ts_ctrl, deriv, T, times, out + (size_t)b0 * T * 3);
+    }
     return (int)hipGetLastError();
 }
 
