@@ -204,6 +204,17 @@ int vigo_optimize(vigo_handle_t h, int B, int N, double* ctrl,
                   double* out_x, int32_t* out_status, double* out_fx,
                   int32_t* out_iters, int32_t* out_evals);
 
+/*
+ * Validation of the CSR lists a solve will index (they live in device memory, so vigo_optimize / vigo_cost_grad /
+ * vigo_traj_dynamic_collision cannot check them per call): offsets start at 0, never decrease and end within
+ * G guide pairs / O obstacles.  Synchronous (one small kernel and a 4-byte read back) — an integration-time
+ * check, not part of the hot path.  guide_off / obs_off may be NULL (skipped).
+ * Returns the number of violations found (0 = the lists are safe to pass), or a negative vigo_status_t.
+ * No reference counterpart: the reference's vector<vector<>> cannot be inconsistent.
+ */
+int vigo_check_lists(vigo_handle_t h, int B, int N, const int32_t* guide_off, int64_t G,
+                     const int32_t* obs_off, int64_t O);
+
 /* ---- B-spline fit, evaluation and the rebound-loop gates --------------------------- */
 
 /*

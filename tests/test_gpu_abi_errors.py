@@ -257,3 +257,27 @@ def test_extreme_values_in_device_data_do_not_fault(raw):
     assert L.vigo_corridor_check(h, 6, 7, dptr(seg), dptr(ns), dptr(dT), box, 0.1, dptr(cf), dptr(c1), dptr(c2)) == 0
     torch.cuda.synchronize()
     assert set(cf.cpu().numpy().tolist()) <= {0, 1}
+
+
+def test_check_lists_finds_inconsistent_offsets():
+    """vigo_check_lists: the integration-time validator for the CSR lists the solve kernels index"""
+    from trajectory_planner_amd.vigo import Vigo
+    v = Vigo(0)
+    dev = v.device
+    B, N = 5, 32
+    goff = (torch.arange(B * N + 1, dtype=torch.int32, device=dev) // 3).contiguous()
+    G = int(goff[-1].item())
+    ooff = torch.tensor([0, 2, 2, 5, 5, 6], dtype=torch.int32, device=dev)
+    assert v.check_lists(B, N, goff, G, ooff, 6) == 0
+    assert v.check_lists(B, N, None, 0, None, 0) == 0
+    assert v.check_lists(B, N, goff, G - 1, ooff, 6) >= 1            # the last offsets point past the pairs
+    assert v.check_lists(B, N, goff, G, ooff, 5) == 1                # past the obstacles
+    bad = goff.clone(); bad[40] = bad[39] - 1                        # decreasing
+    assert v.check_lists(B, N, bad, G) >= 1
+    bad = goff.clone(); bad[0] = 1                                   # does not start at 0 (and decreases right after)
+    assert v.check_lists(B, N, bad, G) >= 1
+    bad = ooff.clone(); bad[2] = -4
+    assert v.check_lists(B, N, None, 0, bad, 6) >= 1
+    with pytest.raises(ValueError):
+        v.check_lists(B, N, goff[:-1].contiguous(), G)
+    v.close()

@@ -70,6 +70,7 @@ PROTOTYPES = {
     "vigo_set_metric_bounds": (_i, [_vp, _d3, _d3]),
     "vigo_query_points": (_i, [_vp, _i, _i64, _vp, _vp]),
     "vigo_guides_unknown": (_i, [_vp, _i64, _vp, _vp]),
+    "vigo_check_lists": (_i, [_vp, _i, _i, _vp, _i64, _vp, _i64]),
     "vigo_cost_grad": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "vigo_optimize": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vigo_bspline_fit": (_i, [_vp, _i, _i, _d, _vp, _vp, _vp]),

@@ -359,6 +359,20 @@ int vigo_guides_unknown(vigo_handle_t h, int64_t G, const double* guide_pv, uint
     return VIGO_OK;
 }
 
+int vigo_check_lists(vigo_handle_t h, int B, int N, const int32_t* guide_off, int64_t G, const int32_t* obs_off, int64_t O) {
+    if (!h) return VIGO_ERR_INVALID_ARG;
+    if (B < 0 || N < 1 || G < 0 || O < 0) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_check_lists: bad argument");
+    if (B == 0 || (!guide_off && !obs_off)) return 0;
+    int rc = ensure_scratch(h, 64);
+    if (rc) return rc;
+    int* bad = static_cast<int*>(h->scratch);
+    VIGO_HIP(h, (hipError_t)vigo::launch_check_lists(h->stream, B, N, guide_off, G, obs_off, O, bad));
+    int host_bad = 0;
+    VIGO_HIP(h, hipMemcpyAsync(&host_bad, bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    VIGO_HIP(h, hipStreamSynchronize(h->stream));
+    return host_bad;
+}
+
 /* ---- ViGO cost / gradient / solve ----------------------------------------------------- */
 
 int vigo_cost_grad(vigo_handle_t h, int B, int N, const double* ctrl, const int32_t* guide_off,

@@ -108,6 +108,9 @@ int launch_corridor_check(hipStream_t s, const GridView& g, int S, int deg, cons
                           double map_res, uint8_t* out_flag, int32_t* out_first, int32_t* out_count);
 int launch_box_points(hipStream_t s, const GridView& g, int64_t M, const double* pts, const double box[3],
                       double map_res, uint8_t* out);
+// counts CSR violations of guide_off[B*N+1] / obs_off[B+1] into *bad (device int, zeroed by the launcher)
+int launch_check_lists(hipStream_t s, int B, int N, const int32_t* guide_off, int64_t G, const int32_t* obs_off, int64_t O,
+                       int* bad);
 int launch_esdf_query(hipStream_t s, const EsdfView& e, int64_t Q, const double* pts,
                       double* out_dist, double* out_grad);
 // row-major [nx][ny][nz] -> the bricked layout of EsdfView

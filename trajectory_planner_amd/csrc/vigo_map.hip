@@ -131,6 +131,17 @@ __global__ void k_merge_bit0(int nz, int nzw, size_t n_words, const uint32_t* __
     }
 }
 
+// CSR offsets off[n]: off[0] == 0, non-decreasing, off[n-1] <= total; every violation is counted
+__global__ void k_check_offsets(const int32_t* __restrict__ off, int64_t n, int64_t total, int* __restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t v = off[i];
+    bool wrong = v < 0 || (int64_t)v > total;
+    if (i == 0) wrong = wrong || v != 0;
+    else wrong = wrong || v < off[i - 1];
+    if (wrong) atomicAdd(bad, 1);
+}
+
 __global__ void k_query_points(GridView g, int plane, int64_t Q, const double* __restrict__ pts,
                                int stride, uint8_t* __restrict__ out) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -251,6 +262,22 @@ int launch_inflate(hipStream_t s, int nx, int ny, int nz, uint8_t* vox, uint32_t
     hipLaunchKernelGGL(k_dilate_bits_rows, dim3(gw), dim3(256), 0, s, nw, (size_t)nzw, ny, ry, planeB, planeA);
     hipLaunchKernelGGL(k_dilate_bits_rows, dim3(gw), dim3(256), 0, s, nw, (size_t)ny * nzw, nx, rx, planeA, planeB);
     hipLaunchKernelGGL(k_merge_bit0, dim3(gw), dim3(256), 0, s, nz, nzw, nw, planeB, vox);
+    return (int)hipGetLastError();
+}
+
+int launch_check_lists(hipStream_t s, int B, int N, const int32_t* guide_off, int64_t G, const int32_t* obs_off, int64_t O,
+                       int* bad) {
+    hipError_t e = hipMemsetAsync(bad, 0, sizeof(int), s);
+    if (e != hipSuccess) return (int)e;
+    const int block = 256;
+    if (guide_off) {
+        const int64_t n = (int64_t)B * N + 1;
+        hipLaunchKernelGGL(k_check_offsets, dim3((unsigned)((n + block - 1) / block)), dim3(block), 0, s, guide_off, n, G, bad);
+    }
+    if (obs_off) {
+        const int64_t n = (int64_t)B + 1;
+        hipLaunchKernelGGL(k_check_offsets, dim3((unsigned)((n + block - 1) / block)), dim3(block), 0, s, obs_off, n, O, bad);
+    }
     return (int)hipGetLastError();
 }
 

@@ -196,6 +196,18 @@ class Vigo:
                 _ptr(obs_off, torch.int32, "obs_off", d), _ptr(obs, torch.float64, "obs", d), n_shared,
                 _ptr(weights, torch.float64, "weights", d))
 
+    def check_lists(self, B: int, N: int, guide_off=None, n_pairs: int = 0, obs_off=None, n_obs: int = 0) -> int:
+        """vigo_check_lists: number of CSR violations in guide_off [B*N+1] / obs_off [B+1] (0 = safe to pass)."""
+        if guide_off is not None and guide_off.numel() != B * N + 1:
+            raise ValueError("guide_off must have B*N+1 entries")
+        if obs_off is not None and obs_off.numel() != B + 1:
+            raise ValueError("obs_off must have B+1 entries")
+        rc = self._lib.vigo_check_lists(self._h, B, N, _ptr(guide_off, torch.int32, "guide_off", self.device), int(n_pairs),
+                                        _ptr(obs_off, torch.int32, "obs_off", self.device), int(n_obs))
+        if rc < 0:
+            self._check(rc, "vigo_check_lists")
+        return rc
+
     def cost_grad(self, ctrl, guide_off=None, guide_pv=None, guide_unk=None, obs_off=None, obs=None,
                   weights=None, want_terms=True):
         """vigo_cost_grad: returns (cost[B], grad[B,N-6,3], terms[B,4] or None)."""
