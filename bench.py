@@ -373,6 +373,9 @@ def main():
                          "byte_model": "SURVEY.md §8(d) streaming model x fp64 (state streamed per BLAS-1 pass, as the CPU "
                                        "reference does); the kernel keeps that state in LDS/VGPRs, so HBM sees only the "
                                        "compulsory bytes below",
+                         "limiter": "instruction issue of one wavefront per SIMD (VALU busy 61 %, memory waits 2 %: "
+                                    "profiles/README.md); the HBM fraction above is the SURVEY's streaming model, not what the "
+                                    "kernel is bound by",
                          "compulsory_bytes_per_launch": compulsory,
                          "compulsory_frac": compulsory / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
