@@ -281,3 +281,34 @@ def test_check_lists_finds_inconsistent_offsets():
     with pytest.raises(ValueError):
         v.check_lists(B, N, goff[:-1].contiguous(), G)
     v.close()
+
+
+def test_python_wrapper_refuses_mis_shaped_tensors(vigo_handle):
+    """the kernels index by the extents the wrapper derives: a tensor of another shape must never reach them"""
+    v = vigo_handle
+    dev = v.device
+    z = lambda *shape, dtype=torch.float64: torch.zeros(*shape, dtype=dtype, device=dev)
+    v.set_grid(z(8, 8, 40, dtype=torch.uint8), np.zeros(3), 0.1)
+    for call in (lambda: v.query_points(z(5, 2)),
+                 lambda: v.guides_unknown(z(5, 3)),
+                 lambda: v.optimize(z(2, 32, 3), z(2 * 32 + 1, dtype=torch.int32), z(4, 5)),
+                 lambda: v.optimize(z(2, 32, 3), obs=z(3, 8)),
+                 lambda: v.optimize(z(2, 32, 3), z(2 * 32 + 1, dtype=torch.int32), z(4, 6), z(3, dtype=torch.uint8)),
+                 lambda: v.bspline_fit(z(2, 8, 3), z(2, 3, 3)),
+                 lambda: v.bspline_eval(z(2, 8, 2), z(4)),
+                 lambda: v.traj_collision(z(2, 8), 0.05),
+                 lambda: v.traj_dynamic_collision(z(2, 8, 3), 0.05, z(2, dtype=torch.int32), z(1, 9)),
+                 lambda: v.ctrl_occupancy(z(2, 8, 4)),
+                 lambda: v.minsnap(z(2, 4, 3), z(2, 4)),
+                 lambda: v.minsnap(z(2, 4, 3), conds=z(2, 4, 2)),
+                 lambda: v.corridor_check(z(3, 3, 8), z(2, dtype=torch.int32), z(3), [0.4, 0.4, 0.2], 0.2),
+                 lambda: v.corridor_check(z(3, 2, 8), z(3, dtype=torch.int32), z(3), [0.4, 0.4, 0.2], 0.2),
+                 lambda: v.box_collision_points(z(5, 4), [0.4, 0.4, 0.2], 0.2),
+                 lambda: v.esdf_query(z(5))):
+        with pytest.raises((ValueError, TypeError)):
+            call()
+    # dtype and placement are checked too
+    with pytest.raises(TypeError):
+        v.query_points(z(5, 3, dtype=torch.float32))
+    with pytest.raises(ValueError):
+        v.query_points(torch.zeros(5, 3, dtype=torch.float64))

@@ -64,6 +64,15 @@ def _ptr(t: Optional[torch.Tensor], dtype, name: str, device=None):
     return C.c_void_p(t.data_ptr())
 
 
+def _shape(t: Optional[torch.Tensor], want, name: str):
+    """the kernels index by these extents: a tensor of another shape is an out-of-range read on the device"""
+    if t is None:
+        return
+    got = tuple(t.shape)
+    if len(got) != len(want) or any(w is not None and g != w for g, w in zip(got, want)):
+        raise ValueError(f"{name}: shape {got}, expected {tuple('*' if w is None else w for w in want)}")
+
+
 @dataclass
 class SolveResult:
     ctrl: torch.Tensor      # [B,N,3] optData_.controlPoints after optimize() (last evaluated point)
@@ -162,6 +171,7 @@ class Vigo:
                     "vigo_set_metric_bounds")
 
     def query_points(self, pts: torch.Tensor, which: int = 0) -> torch.Tensor:
+        _shape(pts, (None, 3), "pts")
         q = pts.shape[0]
         out = torch.empty(q, dtype=torch.uint8, device=self.device)
         self._check(self._lib.vigo_query_points(self._h, which, q, _ptr(pts, torch.float64, "pts", self.device),
@@ -169,6 +179,7 @@ class Vigo:
         return out
 
     def guides_unknown(self, guide_pv: torch.Tensor) -> torch.Tensor:
+        _shape(guide_pv, (None, 6), "guide_pv")
         g = guide_pv.shape[0]
         out = torch.empty(g, dtype=torch.uint8, device=self.device)
         if g:
@@ -187,6 +198,10 @@ class Vigo:
             raise ValueError("obs_off must have B+1 entries")
         if weights is not None and tuple(weights.shape) != (B, 4):
             raise ValueError("weights must be [B,4]")
+        _shape(guide_pv, (None, 6), "guide_pv")
+        _shape(obs, (None, 9), "obs")
+        if guide_unk is not None and guide_pv is not None and guide_unk.numel() != guide_pv.shape[0]:
+            raise ValueError("guide_unk must have one entry per guide pair")
         n_shared = 0
         if obs is not None and obs_off is None:
             n_shared = obs.shape[0]
@@ -247,7 +262,9 @@ class Vigo:
     # ---- spline fit, evaluation and gates -----------------------------------------------
     def bspline_fit(self, points, conds=None, ts=None):
         """bspline::parameterizeToBspline for a batch: points [B,K,3] (+ conds [B,4,3]) -> ctrl [B,K+2,3]"""
+        _shape(points, (None, None, 3), "points")
         B, K, _ = points.shape
+        _shape(conds, (B, 4, 3), "conds")
         ts = float(self.params.ts_ctrl if ts is None else ts)
         out = torch.empty(B, K + 2, 3, dtype=torch.float64, device=self.device)
         self._check(self._lib.vigo_bspline_fit(self._h, B, K, ts, _ptr(points, torch.float64, "points", self.device),
@@ -256,6 +273,7 @@ class Vigo:
         return out
 
     def bspline_eval(self, ctrl, times, deriv=0):
+        _shape(ctrl, (None, None, 3), "ctrl")
         B, N, _ = ctrl.shape
         T = times.numel()
         out = torch.empty(B, T, 3, dtype=torch.float64, device=self.device)
@@ -265,6 +283,7 @@ class Vigo:
         return out
 
     def traj_collision(self, ctrl, dt):
+        _shape(ctrl, (None, None, 3), "ctrl")
         B, N, _ = ctrl.shape
         flag = torch.empty(B, dtype=torch.uint8, device=self.device)
         first = torch.empty(B, dtype=torch.int32, device=self.device)
@@ -274,7 +293,11 @@ class Vigo:
         return flag, first
 
     def traj_dynamic_collision(self, ctrl, dt, obs_off=None, obs=None):
+        _shape(ctrl, (None, None, 3), "ctrl")
         B, N, _ = ctrl.shape
+        _shape(obs, (None, 9), "obs")
+        if obs_off is not None and obs_off.numel() != B + 1:
+            raise ValueError("obs_off must have B+1 entries")
         flag = torch.empty(B, dtype=torch.uint8, device=self.device)
         ns = obs.shape[0] if (obs is not None and obs_off is None) else 0
         self._check(self._lib.vigo_traj_dynamic_collision(
@@ -284,6 +307,7 @@ class Vigo:
         return flag
 
     def ctrl_occupancy(self, ctrl):
+        _shape(ctrl, (None, None, 3), "ctrl")
         B, N, _ = ctrl.shape
         pt = torch.empty(B, N, dtype=torch.uint8, device=self.device)
         line = torch.empty(B, N, dtype=torch.uint8, device=self.device)
@@ -296,7 +320,10 @@ class Vigo:
     def minsnap(self, waypoints, corridor=None, conds=None, deg=7, diff=4, cont=4, vel=1.0, corridor_res=8.0):
         """polyTrajSolver::solve for a batch of paths: waypoints [T,W,3] (+ corridor [T,W-1], conds [T,4,3])
         -> (coeffs [T,W-1,3,deg+1], knots [T,W], status [T])"""
+        _shape(waypoints, (None, None, 3), "waypoints")
         T, W, _ = waypoints.shape
+        _shape(corridor, (T, W - 1), "corridor")
+        _shape(conds, (T, 4, 3), "conds")
         coeffs = torch.zeros(T, W - 1, 3, deg + 1, dtype=torch.float64, device=self.device)
         knots = torch.zeros(T, W, dtype=torch.float64, device=self.device)
         status = torch.full((T,), -99, dtype=torch.int32, device=self.device)
@@ -310,7 +337,10 @@ class Vigo:
 
     def corridor_check(self, coeffs, n_samp, delT, box, map_res):
         """coeffs [S,3,deg+1] f64, n_samp [S] i32, delT [S] f64 -> (flag u8[S], first i32[S], count i32[S])."""
+        _shape(coeffs, (None, 3, None), "coeffs")
         S, three, d1 = coeffs.shape
+        _shape(n_samp, (S,), "n_samp")
+        _shape(delT, (S,), "delT")
         flag = torch.empty(S, dtype=torch.uint8, device=self.device)
         first = torch.empty(S, dtype=torch.int32, device=self.device)
         count = torch.empty(S, dtype=torch.int32, device=self.device)
@@ -323,6 +353,7 @@ class Vigo:
 
     def box_collision_points(self, pts, box, map_res):
         """vigo_box_collision_points: pts [M,3] f64 -> uint8 [M]"""
+        _shape(pts, (None, 3), "pts")
         M = pts.shape[0]
         out = torch.empty(M, dtype=torch.uint8, device=self.device)
         self._check(self._lib.vigo_box_collision_points(self._h, M, _ptr(pts, torch.float64, "pts", self.device),
@@ -337,6 +368,7 @@ class Vigo:
                                             _ptr(dist, torch.float32, "dist", self.device)), "vigo_set_esdf")
 
     def esdf_query(self, pts: torch.Tensor):
+        _shape(pts, (None, 3), "pts")
         q = pts.shape[0]
         d = torch.empty(q, dtype=torch.float64, device=self.device)
         g = torch.empty(q, 3, dtype=torch.float64, device=self.device)
