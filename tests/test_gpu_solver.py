@@ -228,6 +228,33 @@ def test_fp32_mode_cost_and_statistics(vigo_handle, small_world):
     v.set_precision(PREC_F64)
 
 
+@pytest.mark.parametrize("N,B", [(32, 4100), (64, 2100)])
+def test_fp32_large_batches_use_the_two_wave_kernel_with_identical_results(vigo_handle, small_world, N, B):
+    """fp32 state on batches with more wavefronts than the chip has SIMDs runs the register-capped instantiation
+    (two waves per SIMD, scratch spills): the same arithmetic — every trajectory bit-identical to the same batch
+    solved in slices small enough for the one-wave instantiation."""
+    v = vigo_handle
+    P = default_params()
+    P.max_iterations = 30
+    v.set_params(P)
+    v.set_precision(PREC_F32)
+    b = synth.make_bspline_batch(small_world, B, N, 1234 + N, start_range=3.0, n_obs=1)
+    d = batch_to_dev(b, v.device)
+    full = v.optimize(**d)
+    step = 500
+    for lo in range(0, B, step):
+        hi = min(B, lo + step)
+        goff = b.guide_off[lo * N:hi * N + 1]
+        ooff = b.obs_off[lo:hi + 1]
+        sl = synth.Batch(b.ctrl[lo:hi], goff - goff[0], b.guide_pv[goff[0]:goff[-1]], b.guide_unk[goff[0]:goff[-1]],
+                         ooff - ooff[0], b.obs[ooff[0]:ooff[-1]])
+        part = v.optimize(**batch_to_dev(sl, v.device))
+        for k in ("ctrl", "x", "status", "fx", "iters", "evals"):
+            assert torch.equal(getattr(part, k), getattr(full, k)[lo:hi]), (k, lo)
+    assert bool(torch.isfinite(full.ctrl).all())
+    v.set_precision(PREC_F64)
+
+
 @pytest.mark.parametrize("N,B,n_obs", [(32, 300, 0), (20, 64, 2), (64, 40, 1), (100, 12, 0)])
 def test_fast_mode_matches_its_emulation_and_the_reference_gate(vigo_handle, small_world, N, B, n_obs):
     """VIGO_PREC_F64_FAST (explicit fma + one reciprocal per history pair): bit-exact against the

@@ -1,0 +1,23 @@
+"""dev: fp32 vs fp64 solver state at batch sizes that fill every SIMD"""
+import json, os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import numpy as np, torch
+from trajectory_planner_amd import synth
+from trajectory_planner_amd.vigo import Vigo, default_params
+dev = torch.device("cuda", 0)
+T = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+w256 = synth.make_box_world(synth.SEED_BASE + 2, n=256, n_boxes=200)
+for (B, N, prec) in ((16384, 32, 1), (16384, 32, 0), (65536, 32, 1), (65536, 32, 0)):
+    b = synth.make_bspline_batch(w256, B, N, 4242 + N + B, start_range=8.0)
+    P = default_params(); P.max_iterations = 50
+    v = Vigo(0, P, prec)
+    v.set_grid(T(w256.voxels), w256.origin, w256.res)
+    ctrl, goff, gpv = T(b.ctrl), T(b.guide_off), T(b.guide_pv)
+    gunk = v.guides_unknown(gpv)
+    f = lambda: v.optimize(ctrl, goff, gpv, gunk)
+    for _ in range(2): f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): f()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+    print(json.dumps({"B": B, "N": N, "prec": prec, "ms": round(dt * 1e3, 3), "Mtraj_s": round(B / dt / 1e6, 3)}), flush=True)
+    v.close()
