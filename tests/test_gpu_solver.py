@@ -228,16 +228,17 @@ def test_fp32_mode_cost_and_statistics(vigo_handle, small_world):
     v.set_precision(PREC_F64)
 
 
-@pytest.mark.parametrize("N,B", [(32, 4100), (64, 2100)])
-def test_fp32_large_batches_use_the_two_wave_kernel_with_identical_results(vigo_handle, small_world, N, B):
-    """fp32 state on batches with more wavefronts than the chip has SIMDs runs the register-capped instantiation
-    (two waves per SIMD, scratch spills): the same arithmetic — every trajectory bit-identical to the same batch
-    solved in slices small enough for the one-wave instantiation."""
+@pytest.mark.parametrize("N,B,prec", [(32, 4100, PREC_F32), (64, 2100, PREC_F32), (16, 4100, PREC_F64), (20, 4100, 2)])
+def test_large_batches_use_the_two_wave_kernel_with_identical_results(vigo_handle, small_world, N, B, prec):
+    """Batches with more wavefronts than the chip has SIMDs whose history leaves room for eight waves per CU (fp32
+    state, or short fp64 trajectories) run the register-capped instantiation (two waves per SIMD, scratch
+    spills): the same arithmetic — every trajectory bit-identical to the same batch solved in slices small
+    enough for the one-wave instantiation."""
     v = vigo_handle
     P = default_params()
     P.max_iterations = 30
     v.set_params(P)
-    v.set_precision(PREC_F32)
+    v.set_precision(prec)
     b = synth.make_bspline_batch(small_world, B, N, 1234 + N, start_range=3.0, n_obs=1)
     d = batch_to_dev(b, v.device)
     full = v.optimize(**d)

@@ -790,10 +790,11 @@ __device__ __forceinline__ int trial_interval(double& xt, double& xf, double& xd
 #define VIGO_TICK(acc) do { } while (0)
 #endif
 
-// WPS = waves per SIMD the register budget is cut for.  1 everywhere (512 registers per lane, no scratch) except
-// for fp32 state on batches larger than the chip's SIMD count: the fp32 history is half the size, so eight waves
-// fit a CU's LDS, and capping the registers at 256 (276 B of scratch per lane) lets two waves share a SIMD's
-// issue slots — +17 % at 65 536 trajectories, but -6 % when every wave has a SIMD to itself anyway.
+// WPS = waves per SIMD the register budget is cut for.  1 (512 registers per lane, no scratch) unless the batch
+// has more waves than the chip has SIMDs AND the history leaves room for eight waves in a CU's LDS (fp32 state,
+// or fp64 trajectories of up to ~21 control points): capping the registers at 256 (a few hundred bytes of
+// scratch per lane) then lets two waves share a SIMD's issue slots — +17 % for fp32 at 65 536 x 32, +36 % for
+// fp64 at 16 384 x 16 — but costs 6 % when every wave has a SIMD to itself anyway.  Same arithmetic, same bits.
 template <typename T, int GROUP, int PPL, bool FAST, int WPS = 1>
 __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevConst* __restrict__ Kp) {
     const DevConst& K = *Kp;  // uniform address: scalar loads at the use sites, not 100+ live SGPRs
@@ -1351,7 +1352,7 @@ static int launch_optimize_t(hipStream_t s, const SolveArgs& a, const DevConst& 
     const size_t lds = optimize_lds_bytes<T, GROUP>(a.N, k.mem_size, PPL, a.obs != nullptr);
     if (lds > kLdsPerWorkgroup) return (int)hipErrorInvalidValue;  // refused earlier by vigo_optimize
     dim3 grid((a.B + tpb - 1) / tpb), block(kWave);
-    if constexpr (sizeof(T) == 4 && PPL == 1) if ((int)grid.x > simd_count()) {   // fp32 state, more waves than SIMDs: two per SIMD
+    if constexpr (PPL == 1) if ((int)grid.x > simd_count() && lds <= kLdsPerWorkgroup / 8) {   // more waves than SIMDs and 8 fit a CU: two per SIMD
         static bool attr2_set = false;
         if (!attr2_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_optimize<T, GROUP, PPL, FAST, 2>),
