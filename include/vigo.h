@@ -311,9 +311,32 @@ int vigo_corridor_check(vigo_handle_t h, int S, int deg, const double* coeffs,
 int vigo_box_collision_points(vigo_handle_t h, int64_t M, const double* pts, const double box[3],
                               double map_res, uint8_t* out);
 
+/*
+ * Replaces: polyTrajSolver::getTrajectory (PS.cpp:1125-1137) -> getPose (PS.cpp:1026-1056), positions only,
+ * for S independent polynomial segments: the sampler vigo_corridor_check runs internally, on its own.
+ *   coeffs, n_samp, delT as in vigo_corridor_check; sample k of segment s is written at index s * stride + k
+ *   (samples k >= stride are not produced);
+ *   out_pos     double[S][stride][3] or NULL   x, y, z as getPose returns them
+ *   out_pos_f32 float [S][stride][3] or NULL   the same after pose2Octomap's cast to octomap::point3d (PO.cpp:634-656)
+ * pow(t, d) of PS.cpp:1035-1039 is evaluated as the correctly rounded power (see vigo_exact_pow below).
+ */
+int vigo_poly_sample(vigo_handle_t h, int S, int deg, const double* coeffs, const int32_t* n_samp,
+                     const double* delT, int stride, double* out_pos, float* out_pos_f32);
+
 /* The reference's sample clock: t_k of `for (t = 0; ...; t += delT)` (PS.cpp:1129), i.e. the
  * k-fold floating-point accumulation, evaluated in closed form (host utility, no GPU). */
 double vigo_accumulated_time(double delT, int64_t k);
+
+/* pow(t, d) of polyTrajSolver::getPose (PS.cpp:1035-1039) for an integer 0 <= d <= 15 as the sampler kernels
+ * evaluate it: the CORRECTLY ROUNDED power (libm's pow returns it or its neighbour, depending on the libm
+ * build).  Host utilities, no GPU:
+ *   vigo_exact_pow          the kernels' two-tier evaluation (NaN for d outside [0, 15]);
+ *   vigo_exact_pow_dd       its first tier alone — the running double-double product — and whether that tier
+ *                           could certify the rounding (*ambiguous = 0) or defers to the second;
+ *   vigo_exact_pow_integer  its second tier alone: exact integer arithmetic, rounded once. */
+double vigo_exact_pow(double t, int d);
+double vigo_exact_pow_dd(double t, int d, int* ambiguous);
+double vigo_exact_pow_integer(double t, int d);
 
 /* ---- ESDF trilinear query (config 5; no reference counterpart) ------- */
 

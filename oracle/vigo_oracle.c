@@ -1008,15 +1008,102 @@ int vgo_box_collision(const vgo_grid_t* g, float px, float py, float pz, const d
     return 0;
 }
 
+/* pow(t, d) of PS.cpp:1035-1039.  Mode 0: libm's pow(), i.e. the reference as it runs on THIS host (glibc's pow
+ * is within 0.51 ulp: the correctly rounded power in ~99.9 % of the cases, its neighbour otherwise, and which one
+ * depends on the libm build).  Mode 1: the correctly rounded power by exact integer arithmetic — the
+ * platform-independent definition the HIP sampler implements (csrc/vigo_exact_pow.hpp).  Written independently of
+ * that header: a base-2^32 big integer with 64-bit accumulation. */
+static int g_pow_mode = 0;
+void vgo_set_pow_mode(int exact) { g_pow_mode = exact ? 1 : 0; }
+int vgo_get_pow_mode(void) { return g_pow_mode; }
+
+double vgo_pow_exact(double t, int d) {
+    if (d <= 0) return 1.0;
+    if (d == 1) return t;
+    if (t != t || t == 0.0 || t == INFINITY || t == -INFINITY) return pow(t, (double)d);   /* exact specials */
+    int e2;
+    double fr = frexp(fabs(t), &e2);                       /* |t| = fr * 2^e2, fr in [0.5, 1) */
+    uint64_t m = (uint64_t)ldexp(fr, 53);                  /* 53-bit integer significand (exact, subnormals too) */
+    long long ex = (long long)e2 - 53;                     /* |t| = m * 2^ex */
+    uint32_t limb[64];
+    int n = 1;
+    memset(limb, 0, sizeof limb);
+    limb[0] = 1;
+    for (int i = 0; i < d; ++i) {                          /* limb <- limb * m, schoolbook in base 2^32 */
+        const uint32_t digit[2] = {(uint32_t)m, (uint32_t)(m >> 32)};
+        uint32_t out[64];
+        memset(out, 0, sizeof out);
+        for (int k = 0; k < 2; ++k) {
+            uint64_t carry = 0;
+            for (int j = 0; j < n; ++j) {
+                const uint64_t cur = (uint64_t)out[j + k] + (uint64_t)limb[j] * digit[k] + carry;
+                out[j + k] = (uint32_t)cur;
+                carry = cur >> 32;
+            }
+            for (int idx = n + k; carry; ++idx) {
+                const uint64_t cur = (uint64_t)out[idx] + carry;
+                out[idx] = (uint32_t)cur;
+                carry = cur >> 32;
+            }
+        }
+        n += 2;
+        while (n > 1 && out[n - 1] == 0) --n;
+        memcpy(limb, out, sizeof out);
+    }
+    long long E = ex * d;                                  /* t^d = limb * 2^E */
+    int topw = n - 1, topb = 31;
+    while (!((limb[topw] >> topb) & 1u)) --topb;
+    long long top = 32LL * topw + topb;                    /* index of the leading bit */
+    long long exp2 = top + E;
+    int neg = (t < 0) && (d & 1);
+    if (exp2 > 1023) return neg ? -INFINITY : INFINITY;
+    long long keep = exp2 >= -1022 ? 53 : 53 - (-1022 - exp2);
+    if (keep < 0) return neg ? -0.0 : 0.0;
+    long long drop = top + 1 - keep;                       /* low bits to round away */
+    uint64_t q = 0;
+    if (drop <= 0) {
+        for (long long i = top; i >= 0; --i) q = (q << 1) | ((limb[i >> 5] >> (i & 31)) & 1u);
+        drop = 0;
+    } else {
+        for (long long i = top; i >= drop; --i) q = (q << 1) | ((limb[i >> 5] >> (i & 31)) & 1u);
+        int half = (limb[(drop - 1) >> 5] >> ((drop - 1) & 31)) & 1u, rest = 0;
+        for (long long i = drop - 2; i >= 0 && !rest; --i) rest = (limb[i >> 5] >> (i & 31)) & 1u;
+        if (half && (rest || (q & 1u))) ++q;               /* round to nearest, ties to even */
+    }
+    double r = ldexp((double)q, (int)(E + drop));          /* representable by construction */
+    return neg ? -r : r;
+}
+
+static inline double POWD(double t, int d) { return g_pow_mode ? vgo_pow_exact(t, d) : pow(t, d); }
+
 void vgo_poly_pos(int deg, const double* cx, const double* cy, const double* cz, double t,
                   double out[3]) {
     double x = 0, y = 0, z = 0;
     for (int d = 0; d < deg + 1; ++d) {
-        x += cx[d] * pow(t, d);
-        y += cy[d] * pow(t, d);
-        z += cz[d] * pow(t, d);
+        const double pw = POWD(t, d);
+        x += cx[d] * pw;
+        y += cy[d] * pw;
+        z += cz[d] * pw;
     }
     out[0] = x; out[1] = y; out[2] = z;
+}
+
+/* PS.cpp:1125-1137 for S segments: sample k of segment s at out[(s * stride + k) * 3], accumulated clock */
+void vgo_poly_sample(int S, int deg, const double* coeffs, const int32_t* n_samp, const double* delT, int stride,
+                     double* out_pos, float* out_f32) {
+    for (int s = 0; s < S; ++s) {
+        const double* c = coeffs + (size_t)s * 3 * (deg + 1);
+        double t = 0;
+        for (int k = 0; k < n_samp[s] && k < stride; ++k) {
+            double p[3];
+            vgo_poly_pos(deg, c, c + (deg + 1), c + 2 * (deg + 1), t, p);
+            for (int a = 0; a < 3; ++a) {
+                if (out_pos) out_pos[((size_t)s * stride + k) * 3 + a] = p[a];
+                if (out_f32) out_f32[((size_t)s * stride + k) * 3 + a] = (float)p[a];
+            }
+            t += delT[s];
+        }
+    }
 }
 
 int vgo_corridor_check_segment(const vgo_grid_t* g, int deg, const double* coeffs, int n_samp,
@@ -1039,6 +1126,18 @@ int vgo_corridor_check_segment(const vgo_grid_t* g, int deg, const double* coeff
     if (first_idx) *first_idx = first;
     if (count) *count = cnt;
     return cnt > 0;
+}
+
+void vgo_corridor_check_batch(const vgo_grid_t* g, int S, int deg, const double* coeffs, const int32_t* n_samp,
+                              const double* delT, const double box[3], double map_res, uint8_t* flag,
+                              int32_t* first, int32_t* count) {
+    for (int s = 0; s < S; ++s) {
+        int fi = -1, cn = 0;
+        flag[s] = (uint8_t)vgo_corridor_check_segment(g, deg, coeffs + (size_t)s * 3 * (deg + 1), n_samp[s], delT[s], box,
+                                                      map_res, &fi, &cn);
+        if (first) first[s] = fi;
+        if (count) count[s] = cn;
+    }
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -1081,6 +1180,11 @@ void vgo_esdf_query(int nx, int ny, int nz, const double origin[3], double res, 
     out_g[1] = (gy0 * (1 - f[2]) + gy1 * f[2]) / res;
     /* d/dz */
     out_g[2] = (c1 - c0) / res;
+}
+
+void vgo_esdf_query_batch(int nx, int ny, int nz, const double origin[3], double res, const float* dist, int64_t Q,
+                          const double* pts, double* out_d, double* out_g) {
+    for (int64_t q = 0; q < Q; ++q) vgo_esdf_query(nx, ny, nz, origin, res, dist, pts + 3 * q, out_d + q, out_g + 3 * q);
 }
 
 /* ------------------------------------------------------------------------------------ */

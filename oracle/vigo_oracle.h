@@ -127,6 +127,17 @@ int vgo_box_collision(const vgo_grid_t* g, float px, float py, float pz,
 /* PS.cpp:1026-1056 position of one segment polynomial at local time t */
 void vgo_poly_pos(int deg, const double* cx, const double* cy, const double* cz, double t,
                   double out[3]);
+/* pow(t, d) inside vgo_poly_pos: 0 = libm pow() (the reference on this host), 1 = the correctly rounded power
+ * by exact integer arithmetic (what the HIP sampler implements) */
+void vgo_set_pow_mode(int exact);
+int vgo_get_pow_mode(void);
+double vgo_pow_exact(double t, int d);
+/* PS.cpp:1125-1137 positions of S segments (fp64 and/or after pose2Octomap's float cast) */
+void vgo_poly_sample(int S, int deg, const double* coeffs, const int32_t* n_samp, const double* delT, int stride,
+                     double* out_pos, float* out_f32);
+void vgo_corridor_check_batch(const vgo_grid_t* g, int S, int deg, const double* coeffs, const int32_t* n_samp,
+                              const double* delT, const double box[3], double map_res, uint8_t* flag,
+                              int32_t* first, int32_t* count);
 /* PO.cpp:634-656 restricted to one segment sampled with accumulated t += delT */
 int vgo_corridor_check_segment(const vgo_grid_t* g, int deg, const double* coeffs,
                                int n_samp, double delT, const double box[3], double map_res,
@@ -135,6 +146,9 @@ int vgo_corridor_check_segment(const vgo_grid_t* g, int deg, const double* coeff
 /* config 5: trilinear ESDF value + gradient (no reference counterpart) */
 void vgo_esdf_query(int nx, int ny, int nz, const double origin[3], double res,
                     const float* dist, const double p[3], double* out_d, double out_g[3]);
+
+void vgo_esdf_query_batch(int nx, int ny, int nz, const double origin[3], double res, const float* dist, int64_t Q,
+                          const double* pts, double* out_d, double* out_g);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,12 @@ def oracle():
         L.vgo_corridor_check_segment.argtypes = [C.POINTER(Grid), C.c_int, _dp, C.c_int, C.c_double, _dp, C.c_double,
                                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.vgo_esdf_query.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_double, C.POINTER(C.c_float), _dp, _dp, _dp]
+        L.vgo_esdf_query_batch.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_double, C.POINTER(C.c_float), C.c_int64, _dp, _dp, _dp]
+        L.vgo_set_pow_mode.argtypes = [C.c_int]
+        L.vgo_pow_exact.restype = C.c_double
+        L.vgo_pow_exact.argtypes = [C.c_double, C.c_int]
+        L.vgo_poly_sample.argtypes = [C.c_int, C.c_int, _dp, _ip, _dp, C.c_int, _dp, C.POINTER(C.c_float)]
+        L.vgo_corridor_check_batch.argtypes = [C.POINTER(Grid), C.c_int, C.c_int, _dp, _ip, _dp, _dp, C.c_double, _up, _ip, _ip]
         _oracle = L
     return _oracle
 
@@ -190,6 +196,54 @@ def bspline_fit_batch(points, ts, conds=None):
     O.vgo_bspline_fit_batch.restype = None
     O.vgo_bspline_fit_batch(B, K, float(ts), _d(pts), _d(cd), _d(out))
     return out
+
+
+class pow_mode:
+    """context manager: pow(t, d) of the polynomial sampler as the correctly rounded power (True) or libm's (False)"""
+
+    def __init__(self, exact=True):
+        self.exact = exact
+
+    def __enter__(self):
+        self.prev = oracle().vgo_get_pow_mode()
+        oracle().vgo_set_pow_mode(1 if self.exact else 0)
+
+    def __exit__(self, *a):
+        oracle().vgo_set_pow_mode(self.prev)
+
+
+def poly_sample(coeffs, n_samp, delT, stride, f32=False):
+    """oracle vgo_poly_sample: positions [S,stride,3] (float64, or float32 after pose2Octomap's cast)"""
+    co = _c(coeffs, np.float64)
+    S, _, d1 = co.shape
+    ns, dl = _c(n_samp, np.int32), _c(delT, np.float64)
+    out = np.zeros((S, stride, 3), dtype=np.float32 if f32 else np.float64)
+    oracle().vgo_poly_sample(S, d1 - 1, _d(co), _i(ns), _d(dl), int(stride), None if f32 else _d(out),
+                             out.ctypes.data_as(C.POINTER(C.c_float)) if f32 else None)
+    return out
+
+
+def corridor_check_batch(grid, coeffs, n_samp, delT, box, map_res):
+    """oracle checker over S segments -> (flag u8[S], first i32[S], count i32[S])"""
+    co = _c(coeffs, np.float64)
+    S, _, d1 = co.shape
+    ns, dl, bx = _c(n_samp, np.int32), _c(delT, np.float64), _c(box, np.float64)
+    flag, first, count = np.zeros(S, dtype=np.uint8), np.zeros(S, dtype=np.int32), np.zeros(S, dtype=np.int32)
+    oracle().vgo_corridor_check_batch(C.byref(grid), S, d1 - 1, _d(co), _i(ns), _d(dl), _d(bx), float(map_res), _u(flag),
+                                      _i(first), _i(count))
+    return flag, first, count
+
+
+def esdf_query_batch(dist, origin, res, pts):
+    """oracle trilinear ESDF over Q points -> (d [Q], grad [Q,3])"""
+    ds = np.ascontiguousarray(dist, dtype=np.float32)
+    pt = _c(pts, np.float64)
+    org = _c(origin, np.float64)
+    Q = pt.shape[0]
+    d, g = np.zeros(Q), np.zeros((Q, 3))
+    oracle().vgo_esdf_query_batch(ds.shape[0], ds.shape[1], ds.shape[2], _d(org), float(res),
+                                  ds.ctypes.data_as(C.POINTER(C.c_float)), Q, _d(pt), _d(d), _d(g))
+    return d, g
 
 
 def make_grid(world):

@@ -79,6 +79,56 @@ def test_accumulated_time_equals_the_reference_loop():
     assert lib.vigo_accumulated_time(0.0, 5) == 0.0
 
 
+def test_exact_pow_is_the_correctly_rounded_power(olib):
+    """vigo_exact_pow (the sampler kernels' pow(t, d), polyTrajSolver.cpp:1035-1039) and the oracle's independent
+    vgo_pow_exact both equal the exactly rounded rational power; the double-double tier alone is right whenever it
+    does not report itself ambiguous; libm's pow is the same value or its neighbour."""
+    import math
+    from fractions import Fraction
+    import random
+    lib = _lib.load()
+    O = olib.oracle()
+    rnd = random.Random(11)
+    ts = [rnd.uniform(0.0, 6.0) for _ in range(3000)] + [rnd.uniform(-3.0, 3.0) for _ in range(500)]
+    ts += [math.ldexp(rnd.uniform(0.5, 1.0), rnd.randint(-1074, 1023)) for _ in range(500)]       # whole exponent range
+    ts += [float(rnd.randint(1, 1 << 20)) * 2.0 ** rnd.randint(-30, 5) for _ in range(500)]       # short significands: exact powers, ties
+    ts += [5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, 1.0, -1.0, 2.0, 0.5, 3.0, 1.5 * 2.0 ** -76]
+    off_by_one, n = 0, 0
+    for t in ts:
+        ft = Fraction(t)
+        for d in range(0, 16):
+            f = ft ** d
+            try:
+                want = f.numerator / f.denominator           # Python's int / int is correctly rounded
+            except OverflowError:
+                want = math.inf if f > 0 else -math.inf
+            assert lib.vigo_exact_pow(t, d) == want, (t.hex(), d)
+            assert lib.vigo_exact_pow_integer(t, d) == want, (t.hex(), d)
+            assert O.vgo_pow_exact(t, d) == want, (t.hex(), d)
+            amb = C.c_int(0)
+            dd = lib.vigo_exact_pow_dd(t, d, C.byref(amb))
+            assert amb.value or dd == want, (t.hex(), d)
+            if d >= 2 and 0.0 < abs(want) < math.inf:
+                n += 1
+                got = math.pow(t, d)
+                if got != want:
+                    off_by_one += 1
+                    assert got in (math.nextafter(want, math.inf), math.nextafter(want, -math.inf))
+    # in the sampler's range the first tier decides practically always (2^-40 per power by design)
+    amb_in_range = 0
+    for t in ts[:3000]:
+        for d in range(2, 8):
+            amb = C.c_int(0)
+            lib.vigo_exact_pow_dd(t, d, C.byref(amb))
+            amb_in_range += amb.value
+    assert amb_in_range == 0
+    assert off_by_one < 0.01 * n          # glibc: ~1e-3 (the reason the device does not chase libm's bits)
+    for t, d, want in ((math.nan, 0, 1.0), (math.inf, 0, 1.0), (-math.inf, 3, -math.inf), (-math.inf, 2, math.inf), (0.0, 5, 0.0)):
+        assert lib.vigo_exact_pow(t, d) == want and O.vgo_pow_exact(t, d) == want
+    assert math.isnan(lib.vigo_exact_pow(math.nan, 3)) and math.isnan(lib.vigo_exact_pow(2.0, 16))
+    assert math.copysign(1.0, lib.vigo_exact_pow(-0.0, 3)) == -1.0 and math.copysign(1.0, lib.vigo_exact_pow(-0.0, 2)) == 1.0
+
+
 def test_header_is_plain_c(tmp_path):
     """include/vigo.h must compile as C99 and as C++14 (the reference's standard, CMakeLists.txt:6) on its own:
     no C++ or torch types at the boundary"""

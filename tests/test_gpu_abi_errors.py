@@ -307,6 +307,23 @@ def test_python_wrapper_refuses_mis_shaped_tensors(vigo_handle):
                  lambda: v.esdf_query(z(5))):
         with pytest.raises((ValueError, TypeError)):
             call()
+    # a caller-owned SolveResult is written by the kernel: extents, dtype and placement are checked like the inputs'
+    from trajectory_planner_amd.vigo import SolveResult, VigoError
+    good = lambda B, N: SolveResult(None, z(B, N - 6, 3), z(B, dtype=torch.int32), z(B), z(B, dtype=torch.int32), z(B, dtype=torch.int32))
+    v.optimize(z(2, 32, 3), out=good(2, 32))
+    for bad in (good(1, 32), good(2, 20)):
+        with pytest.raises(ValueError):
+            v.optimize(z(2, 32, 3), out=bad)
+    o = good(2, 32)
+    o.status = z(2, dtype=torch.int64)
+    with pytest.raises(TypeError):
+        v.optimize(z(2, 32, 3), out=o)
+    o = good(2, 32)
+    o.fx = torch.zeros(2, dtype=torch.float64)
+    with pytest.raises(ValueError):
+        v.optimize(z(2, 32, 3), out=o)
+    with pytest.raises(VigoError):                     # N < 7 is refused before anything is allocated
+        v.optimize(z(2, 5, 3))
     # dtype and placement are checked too
     with pytest.raises(TypeError):
         v.query_points(z(5, 3, dtype=torch.float32))

@@ -202,7 +202,7 @@ def test_determinism_permutation_and_subbatch_invariance(vigo_handle, small_worl
     rel = rel_err_per_traj(r1.ctrl.cpu().numpy(), ref["ctrl"])
     print(f"\nconfig 2 (1024x32, 50 it) vs reference-order oracle: median {np.median(rel):.2e} p99 {np.quantile(rel, .99):.2e} "
           f"max {rel.max():.2e} within 1e-4: {(rel <= TOL).mean():.4f}")
-    assert (rel <= TOL).mean() >= 0.995
+    assert (rel <= TOL).all()          # every trajectory of the BASELINE batch (measured: max 1.2e-6)
 
 
 def test_fp32_mode_cost_and_statistics(vigo_handle, small_world):
@@ -315,7 +315,7 @@ def test_baseline_sizes_in_full(vigo_handle, name, n, n_boxes, centre, B, N, sta
     rel = rel_err_per_traj(g["ctrl"], ref["ctrl"])
     print(f"\n[{name}: {B} x {N}] vs reference-order oracle: median {np.median(rel):.2e} p99 {np.quantile(rel, .99):.2e} "
           f"max {rel.max():.2e}; within 1e-4: {(rel <= TOL).mean() * 100:.2f} %")
-    assert (rel <= TOL).mean() >= 0.995 and np.median(rel) < 1e-8
+    assert (rel <= TOL).all() and np.median(rel) < 1e-8     # 100 % (measured: max 1.2e-6 / 2.1e-6)
     # fixed boundary control points never move (BT.cpp:690-691)
     assert np.array_equal(g["ctrl"][:, :3], b.ctrl[:, :3]) and np.array_equal(g["ctrl"][:, -3:], b.ctrl[:, -3:])
 

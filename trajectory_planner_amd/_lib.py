@@ -81,7 +81,11 @@ PROTOTYPES = {
     "vigo_minsnap": (_i, [_vp, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vigo_corridor_check": (_i, [_vp, _i, _i, _vp, _vp, _vp, _d3, _d, _vp, _vp, _vp]),
     "vigo_box_collision_points": (_i, [_vp, _i64, _vp, _d3, _d, _vp]),
+    "vigo_poly_sample": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "vigo_accumulated_time": (_d, [_d, _i64]),
+    "vigo_exact_pow": (_d, [_d, _i]),
+    "vigo_exact_pow_dd": (_d, [_d, _i, C.POINTER(_i)]),
+    "vigo_exact_pow_integer": (_d, [_d, _i]),
     "vigo_set_esdf": (_i, [_vp, _i, _i, _i, _d3, _d, _vp]),
     "vigo_esdf_query": (_i, [_vp, _i64, _vp, _vp, _vp]),
 }

@@ -7,6 +7,7 @@
 
 #include <vector>
 
+#include "vigo_exact_pow.hpp"
 #include "vigo_exact_time.hpp"
 #include "vigo_internal.hpp"
 
@@ -167,6 +168,22 @@ extern "C" {
 
 int vigo_abi_version(void) { return 1; }
 double vigo_accumulated_time(double delT, int64_t k) { return vigo::accumulated_time(delT, k); }
+double vigo_exact_pow_dd(double t, int d, int* ambiguous) {
+    // the first tier as the sampler kernels run it: t^0 = 1, t^1 = t, then the running double-double product
+    bool amb = false;
+    double hi = d <= 0 ? 1.0 : t, lo = 0.0;
+    for (int i = 2; i <= d && i <= 15; ++i) amb |= vigo::pow_step(hi, lo, t);
+    if (ambiguous) *ambiguous = amb ? 1 : 0;
+    return hi;
+}
+double vigo_exact_pow(double t, int d) {
+    if (d < 0 || d > 15) return NAN;
+    if (t == 0.0) return vigo::pow_exact(t, d);   // (the first tier does not track the sign of a zero result)
+    int amb = 0;
+    const double v = vigo_exact_pow_dd(t, d, &amb);
+    return amb ? vigo::pow_exact(t, d) : v;
+}
+double vigo_exact_pow_integer(double t, int d) { return (d < 0 || d > 15) ? NAN : vigo::pow_exact(t, d); }
 const char* vigo_build_arch(void) { return "gfx950"; }
 
 void vigo_default_params(vigo_params_t* p) {
@@ -211,11 +228,19 @@ int vigo_create(vigo_handle_t* out, int device_ordinal) {
     h->device = device_ordinal;
     vigo_default_params(&h->params);
     h->dc = vigo::make_dev_const(h->params);
-    if (hipMalloc(reinterpret_cast<void**>(&h->dc_dev), sizeof(vigo::DevConst)) != hipSuccess ||
-        hipMemcpy(h->dc_dev, &h->dc, sizeof(vigo::DevConst), hipMemcpyHostToDevice) != hipSuccess) {
-        delete h;
+    bool ok = hipMalloc(reinterpret_cast<void**>(&h->dc_dev), sizeof(vigo::DevConst)) == hipSuccess &&
+              hipMemcpy(h->dc_dev, &h->dc, sizeof(vigo::DevConst), hipMemcpyHostToDevice) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&h->dc_stage), vigo_context::kDcSlots * sizeof(vigo::DevConst)) == hipSuccess;
+    for (int i = 0; ok && i < vigo_context::kDcSlots; ++i)
+        ok = hipEventCreateWithFlags(&h->dc_event[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)vigo_destroy(h);
         return VIGO_ERR_HIP;
     }
+    // launch geometry of this handle's device (vigo_solver.hip decides one or two waves per SIMD from it)
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0)
+        h->launch.simd_count = 4 * cus;
     *out = h;
     return VIGO_OK;
 }
@@ -229,13 +254,22 @@ int vigo_destroy(vigo_handle_t h) {
     if (h->times_dev) (void)hipFree(h->times_dev);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->dc_dev) (void)hipFree(h->dc_dev);
+    for (int i = 0; i < vigo_context::kDcSlots; ++i)
+        if (h->dc_event[i]) (void)hipEventDestroy(h->dc_event[i]);
+    if (h->dc_stage) (void)hipHostFree(h->dc_stage);
     delete h;
     return VIGO_OK;
 }
 
 int vigo_set_stream(vigo_handle_t h, void* hip_stream) {
     if (!h) return VIGO_ERR_INVALID_ARG;
-    h->stream = static_cast<hipStream_t>(hip_stream);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (s != h->stream) {
+        // the handle's device-side state (solver constants, cached tables) is updated in stream order on the bound
+        // stream: work still queued on the old stream must not see updates issued on the new one
+        VIGO_HIP(h, hipStreamSynchronize(h->stream));
+        h->stream = s;
+    }
     return VIGO_OK;
 }
 
@@ -261,10 +295,18 @@ int vigo_set_params(vigo_handle_t h, const vigo_params_t* p) {
         p->xtol < 0. || p->max_linesearch <= 0 || p->max_iterations < 0)
         return fail(h, VIGO_ERR_INVALID_ARG, "invalid L-BFGS parameter (see lbfgs.hpp:1060-1104)");
     if (memcmp(&h->params, p, sizeof(*p)) == 0) return VIGO_OK;   // unchanged (callers re-send them per round): no copy, no sync
+    // The kernels read the constants through dc_dev for the whole solve, and launches are asynchronous: the
+    // refresh is therefore ordered WITH the bound stream (an async copy from a pinned staging slot), after every
+    // solve already queued there and before every later one — a blocking copy on the null stream would change
+    // max_iterations, the weights, ... under a solve still running on a non-blocking stream.
+    const int slot = h->dc_next;
+    VIGO_HIP(h, hipEventSynchronize(h->dc_event[slot]));          // the slot's previous copy (4 refreshes ago) has left it
+    h->dc_stage[slot] = vigo::make_dev_const(*p);
+    VIGO_HIP(h, hipMemcpyAsync(h->dc_dev, &h->dc_stage[slot], sizeof(vigo::DevConst), hipMemcpyHostToDevice, h->stream));
+    VIGO_HIP(h, hipEventRecord(h->dc_event[slot], h->stream));
+    h->dc_next = (slot + 1) % vigo_context::kDcSlots;
     h->params = *p;
-    h->dc = vigo::make_dev_const(h->params);
-    // blocking copy: every launch issued after this call sees the new constants, whatever its stream
-    VIGO_HIP(h, hipMemcpy(h->dc_dev, &h->dc, sizeof(vigo::DevConst), hipMemcpyHostToDevice));
+    h->dc = h->dc_stage[slot];
     return VIGO_OK;
 }
 
@@ -412,7 +454,7 @@ int vigo_optimize(vigo_handle_t h, int B, int N, double* ctrl, const int32_t* gu
     a.out_iters = out_iters; a.out_evals = out_evals;
     if (vigo::optimize_lds_requirement(N, h->params.mem_size, h->precision) > (size_t)160 * 1024)
         return fail(h, VIGO_ERR_UNSUPPORTED_N, "the L-BFGS history of N control points x mem_size does not fit the 160 KiB LDS of a CU");
-    VIGO_HIP(h, (hipError_t)vigo::launch_optimize(h->stream, a, h->dc, h->dc_dev, h->precision));
+    VIGO_HIP(h, (hipError_t)vigo::launch_optimize(h->stream, a, h->dc, h->dc_dev, h->precision, h->launch));
     return VIGO_OK;
 }
 
@@ -510,7 +552,7 @@ int vigo_minsnap(vigo_handle_t h, int T, int W, int deg, int diff, int cont, dou
     if (cont < 2 || me > 64 || me > K * 8 || K * 8 - me > 40 || vigo::minsnap_lds_bytes(W, cont) > (size_t)160 * 1024)
         return fail(h, VIGO_ERR_UNSUPPORTED, "vigo_minsnap: continuity degree outside what one wavefront / 160 KiB of LDS holds");
     VIGO_HIP(h, (hipError_t)vigo::launch_minsnap(h->stream, T, W, deg, diff, cont, desired_vel, corridor_res, waypoints, corridor, conds,
-                                                 out_coeffs, out_knots, out_status));
+                                                 out_coeffs, out_knots, out_status, h->launch));
     return VIGO_OK;
 }
 
@@ -530,6 +572,15 @@ int vigo_corridor_check(vigo_handle_t h, int S, int deg, const double* coeffs, c
     }
     VIGO_HIP(h, (hipError_t)vigo::launch_corridor_check(h->stream, h->grid, S, deg, coeffs, n_samp, delT, box, map_res,
                                                         out_flag, out_first, out_count));
+    return VIGO_OK;
+}
+
+int vigo_poly_sample(vigo_handle_t h, int S, int deg, const double* coeffs, const int32_t* n_samp, const double* delT,
+                     int stride, double* out_pos, float* out_pos_f32) {
+    if (!h) return VIGO_ERR_INVALID_ARG;
+    if (S < 0 || deg < 0 || deg > 15 || stride < 0 || (S > 0 && stride > 0 && (!coeffs || !n_samp || !delT || (!out_pos && !out_pos_f32))))
+        return fail(h, VIGO_ERR_INVALID_ARG, "vigo_poly_sample: bad argument");
+    VIGO_HIP(h, (hipError_t)vigo::launch_poly_sample(h->stream, S, deg, coeffs, n_samp, delT, stride, out_pos, out_pos_f32));
     return VIGO_OK;
 }
 

@@ -13,6 +13,7 @@
 //           every lattice point of the box sweep up in the LDS tile (a segment makes ~10^5
 //           lookups inside a few thousand words).
 // A tile too large for the LDS budget falls back to lookups in the packed planes (L2).
+#include "vigo_exact_pow.hpp"
 #include "vigo_exact_time.hpp"
 #include "vigo_grid.hpp"
 
@@ -40,14 +41,60 @@ struct CorridorArgs {
     SweepConst sweep;
 };
 
-// PS.cpp:1035-1039: x += c[d] * pow(t, d), d ascending (powers by repeated multiplication)
+// ---- the sampler: polyTrajSolver::getPose, PS.cpp:1035-1039 -------------------------------------------
+//   x += c[d] * pow(t, d), d ascending, for the three axes.
+// pow(t, d) is evaluated as THE correctly rounded power (vigo_exact_pow.hpp: running double-double product,
+// certified per power, exact integer arithmetic for the 2^-40 of cases that cannot be certified), so the sample
+// positions — and with them the float coordinates, voxel keys, flags and indices the checker derives — are a
+// function of the inputs alone, whatever libm the reference was linked against.
 __device__ __forceinline__ void poly_pos(const double* cf, int deg, double t, double (&p)[3]) {
-    double x = 0, y = 0, z = 0, pw = 1.0;
+    double x = 0, y = 0, z = 0, hi = 1.0, lo = 0.0;
+    bool amb = false;
     for (int d = 0; d <= deg; ++d) {
-        x += cf[d] * pw;
-        y += cf[(kMaxDeg + 1) + d] * pw;
-        z += cf[2 * (kMaxDeg + 1) + d] * pw;
-        pw *= t;
+        if (d == 1) hi = t;
+        else if (d > 1) amb |= pow_step(hi, lo, t);
+        x += cf[d] * hi;
+        y += cf[(kMaxDeg + 1) + d] * hi;
+        z += cf[2 * (kMaxDeg + 1) + d] * hi;
+    }
+    if (__any(amb)) {
+        if (amb) {
+            x = y = z = 0;
+            for (int d = 0; d <= deg; ++d) {
+                const double pw = pow_exact(t, d);
+                x += cf[d] * pw;
+                y += cf[(kMaxDeg + 1) + d] * pw;
+                z += cf[2 * (kMaxDeg + 1) + d] * pw;
+            }
+        }
+    }
+    p[0] = x; p[1] = y; p[2] = z;
+}
+
+// the planner's degree (cfg polynomial_degree: 7): coefficients in registers, same operation order
+__device__ __forceinline__ void poly_pos7(const double (&c7)[3][8], double t, double (&p)[3]) {
+    double pw[8];
+    pw[0] = 1.0;
+    pw[1] = t;
+    double hi = t, lo = 0.0;
+    bool amb = false;
+#pragma unroll
+    for (int d = 2; d < 8; ++d) {
+        amb |= pow_step(hi, lo, t);
+        pw[d] = hi;
+    }
+    if (__any(amb)) {
+        if (amb) {
+#pragma unroll
+            for (int d = 2; d < 8; ++d) pw[d] = pow_exact(t, d);
+        }
+    }
+    double x = 0, y = 0, z = 0;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        x += c7[0][d] * pw[d];
+        y += c7[1][d] * pw[d];
+        z += c7[2][d] * pw[d];
     }
     p[0] = x; p[1] = y; p[2] = z;
 }
@@ -289,23 +336,12 @@ __global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A)
         }
     };
     if (deg == 7) {
-        // the planner's degree (cfg polynomial_degree: 7): coefficients in registers, same operation order
         double c7[3][8];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int d = 0; d < 8; ++d) c7[a][d] = cf[a * (kMaxDeg + 1) + d];
-        walk([&](double t, double (&p)[3]) {
-            double x = 0, y = 0, z = 0, pw = 1.0;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                x += c7[0][d] * pw;
-                y += c7[1][d] * pw;
-                z += c7[2][d] * pw;
-                pw *= t;
-            }
-            p[0] = x; p[1] = y; p[2] = z;
-        });
+        walk([&](double t, double (&p)[3]) { poly_pos7(c7, t, p); });
     } else {
         walk([&](double t, double (&p)[3]) { poly_pos(cf, deg, t, p); });
     }
@@ -318,6 +354,44 @@ __global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A)
         A.out_flag[s] = (uint8_t)(s_count > 0);
         if (A.out_first) A.out_first[s] = s_count > 0 ? s_first : -1;
         if (A.out_count) A.out_count[s] = s_count;
+    }
+}
+
+// ---- the sampler alone: polyTrajSolver::getTrajectory (PS.cpp:1125-1137) for S segments ---------------
+// Same clock (accumulated_time + the reference's t += delT inside a chunk) and the same poly_pos / poly_pos7 as
+// k_corridor, so a parity test of these positions is a parity test of what the checker sweeps.
+__global__ void __launch_bounds__(kBlock) k_poly_sample(int S, int deg, const double* __restrict__ coeffs,
+                                                        const int32_t* __restrict__ n_samp, const double* __restrict__ delT,
+                                                        int stride, double* __restrict__ out_pos, float* __restrict__ out_f32) {
+    __shared__ double cf[3 * (kMaxDeg + 1)];
+    const int s = blockIdx.x;
+    if (s >= S) return;
+    const int tid = threadIdx.x;
+    const int n = min(n_samp[s], stride);
+    const double dT = delT[s];
+    if (tid < 3 * (deg + 1)) {
+        const int ax = tid / (deg + 1), d = tid % (deg + 1);
+        cf[ax * (kMaxDeg + 1) + d] = coeffs[((size_t)s * 3 + ax) * (deg + 1) + d];
+    }
+    __syncthreads();
+    double c7[3][8];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int d = 0; d < 8; ++d) c7[a][d] = deg == 7 ? cf[a * (kMaxDeg + 1) + d] : 0.0;
+    const int n_chunks = (n + kChunk - 1) / kChunk;
+    for (int c = tid; c < n_chunks; c += kBlock) {
+        const int k0 = c * kChunk, k1 = min(n, k0 + kChunk);
+        double t = accumulated_time(dT, k0);
+        for (int k = k0; k < k1; ++k) {
+            double p[3];
+            if (deg == 7) poly_pos7(c7, t, p);
+            else poly_pos(cf, deg, t, p);
+            const size_t o = ((size_t)s * stride + k) * 3;
+            if (out_pos) { out_pos[o] = p[0]; out_pos[o + 1] = p[1]; out_pos[o + 2] = p[2]; }
+            if (out_f32) { out_f32[o] = (float)p[0]; out_f32[o + 1] = (float)p[1]; out_f32[o + 2] = (float)p[2]; }   // pose2Octomap
+            t += dT;
+        }
     }
 }
 
@@ -419,6 +493,13 @@ int launch_corridor_check(hipStream_t s, const GridView& g, int S, int deg, cons
     const int tile_bytes = 32 * 1024;
     A.tile_words_cap = tile_bytes / 4;
     hipLaunchKernelGGL(k_corridor, dim3(S), dim3(kBlock), tile_bytes, s, g, A);
+    return (int)hipGetLastError();
+}
+
+int launch_poly_sample(hipStream_t s, int S, int deg, const double* coeffs, const int32_t* n_samp, const double* delT,
+                       int stride, double* out_pos, float* out_f32) {
+    if (S <= 0 || stride <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_poly_sample, dim3(S), dim3(kBlock), 0, s, S, deg, coeffs, n_samp, delT, stride, out_pos, out_f32);
     return (int)hipGetLastError();
 }
 

@@ -81,10 +81,18 @@ inline size_t esdf_bricked_floats(int nx, int ny, int nz) {
     return (size_t)((nx + 3) / 4) * ((ny + 3) / 4) * ((nz + 3) / 4) * 64;
 }
 
+// Per-handle (= per-device) launch state: which kernel instantiations already had their dynamic-LDS limit raised on
+// the handle's device, and that device's SIMD count.  Nothing of this kind is kept in function statics.
+struct LaunchState {
+    uint64_t lds_attr_set = 0;   // bit per k_optimize instantiation (vigo_solver.hip)
+    bool minsnap_attr_set = false;
+    int simd_count = 0;          // 4 per CU; 0 = unknown
+};
+
 // launchers (each returns hipError_t as int)
 // k: host copy (launch geometry), kd: the same constants in device memory (read by the kernels)
 int launch_cost_grad(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, int precision);
-int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, int precision);
+int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, int precision, LaunchState& L);
 // LDS bytes one solve workgroup needs for N control points (must stay <= 160 KiB)
 size_t optimize_lds_requirement(int N, int mem_size, int precision);
 
@@ -108,6 +116,9 @@ int launch_corridor_check(hipStream_t s, const GridView& g, int S, int deg, cons
                           double map_res, uint8_t* out_flag, int32_t* out_first, int32_t* out_count);
 int launch_box_points(hipStream_t s, const GridView& g, int64_t M, const double* pts, const double box[3],
                       double map_res, uint8_t* out);
+// polyTrajSolver::getTrajectory for S segments: sample k of segment s at out[(s * stride + k) * 3] (fp64 and/or float)
+int launch_poly_sample(hipStream_t s, int S, int deg, const double* coeffs, const int32_t* n_samp, const double* delT,
+                       int stride, double* out_pos, float* out_f32);
 // counts CSR violations of guide_off[B*N+1] / obs_off[B+1] into *bad (device int, zeroed by the launcher)
 int launch_check_lists(hipStream_t s, int B, int N, const int32_t* guide_off, int64_t G, const int32_t* obs_off, int64_t O,
                        int* bad);
@@ -127,7 +138,7 @@ size_t minsnap_lds_bytes(int W, int cont);
 int minsnap_max_waypoints();
 int launch_minsnap(hipStream_t s, int T, int W, int deg, int diff, int cont, double vel, double corridor_res,
                    const double* wp, const double* corridor, const double* conds, double* out_coeffs,
-                   double* out_knots, int32_t* out_status);
+                   double* out_knots, int32_t* out_status, LaunchState& L);
 
 }  // namespace vigo
 
@@ -136,8 +147,14 @@ struct vigo_context {
     hipStream_t stream = nullptr;
     vigo_params_t params;
     vigo::DevConst dc;
-    vigo::DevConst* dc_dev = nullptr;  // device copy, refreshed by vigo_set_params
+    vigo::DevConst* dc_dev = nullptr;  // device copy, refreshed by vigo_set_params IN STREAM ORDER (see there)
+    // pinned staging ring for those refreshes: slot i may be rewritten once dc_event[i] (its last copy) is done
+    static constexpr int kDcSlots = 4;
+    vigo::DevConst* dc_stage = nullptr;   // hipHostMalloc'ed [kDcSlots]
+    hipEvent_t dc_event[kDcSlots] = {};
+    int dc_next = 0;
     int precision = VIGO_PREC_F64;
+    vigo::LaunchState launch;
     std::string last_error;
     // voxel snapshot
     uint32_t* grid_planes = nullptr;

@@ -668,15 +668,14 @@ int minsnap_max_waypoints() { return kMaxSeg + 1; }
 
 int launch_minsnap(hipStream_t s, int T, int W, int deg, int diff, int cont, double vel, double corridor_res,
                    const double* wp, const double* corridor, const double* conds, double* out_coeffs, double* out_knots,
-                   int32_t* out_status) {
+                   int32_t* out_status, LaunchState& L) {
     if (T <= 0) return hipSuccess;
     MinsnapArgs a{T, W, deg, diff, cont, vel, corridor_res, wp, corridor, conds, out_coeffs, out_knots, out_status};
     const size_t lds = minsnap_lds_bytes(W, cont) - 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!L.minsnap_attr_set) {   // per handle = per device (LaunchState), not a function static
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_minsnap), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);  // minus the static __shared__ scalars
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        L.minsnap_attr_set = true;
     }
     hipLaunchKernelGGL(k_minsnap, dim3(T), dim3(kLanes), lds, s, a);
     return (int)hipGetLastError();

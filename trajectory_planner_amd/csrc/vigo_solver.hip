@@ -1332,66 +1332,61 @@ int launch_cost_grad(hipStream_t s, const SolveArgs& a, const DevConst& k, const
     return launch_cost_grad_t<double, false>(s, a, kd);
 }
 
-// SIMDs of the current device (4 per CU); a solver wavefront per SIMD is full occupancy for the fp64 kernels
-static int simd_count() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            n = 4 * cus;
-        else
-            n = 1 << 30;   // unknown: never switch
-    }
-    return n;
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: the "already raised" flags live in the handle
+// (LaunchState, one per handle = per device), never in function statics, so a second device of the same process
+// gets its own.  SLOT numbers one k_optimize instantiation.
+template <typename KernelT>
+static int raise_dynamic_lds(LaunchState& L, int slot, KernelT kernel) {
+    if (L.lds_attr_set & (1ull << slot)) return (int)hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kLdsPerWorkgroup);
+    if (e != hipSuccess) return (int)e;
+    L.lds_attr_set |= 1ull << slot;
+    return (int)hipSuccess;
 }
 
 template <typename T, int GROUP, int PPL, bool FAST>
-static int launch_optimize_t(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd) {
+static int launch_optimize_t(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, LaunchState& L) {
     const int tpb = kWave / GROUP;
     const size_t lds = optimize_lds_bytes<T, GROUP>(a.N, k.mem_size, PPL, a.obs != nullptr);
     if (lds > kLdsPerWorkgroup) return (int)hipErrorInvalidValue;  // refused earlier by vigo_optimize
     dim3 grid((a.B + tpb - 1) / tpb), block(kWave);
-    if constexpr (PPL == 1) if ((int)grid.x > simd_count() && lds <= kLdsPerWorkgroup / 8) {   // more waves than SIMDs and 8 fit a CU: two per SIMD
-        static bool attr2_set = false;
-        if (!attr2_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_optimize<T, GROUP, PPL, FAST, 2>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerWorkgroup);
-            if (e != hipSuccess) return (int)e;
-            attr2_set = true;
-        }
+    // slot = arithmetic (fp32 / fp64 / fp64 fast) x shape (GROUP, PPL) x waves per SIMD
+    const int arith = std::is_same<T, float>::value ? 0 : (FAST ? 2 : 1);
+    const int shape = GROUP == 32 ? 0 : (PPL == 1 ? 1 : (PPL == 2 ? 2 : 3));
+    const int slot = (arith * 4 + shape) * 2;
+    // a solver wavefront per SIMD (4 per CU) is full occupancy for these kernels; unknown SIMD count: never switch
+    const int simds = L.simd_count > 0 ? L.simd_count : (1 << 30);
+    if constexpr (PPL == 1) if ((int)grid.x > simds && lds <= kLdsPerWorkgroup / 8) {   // more waves than SIMDs and 8 fit a CU: two per SIMD
+        int e = raise_dynamic_lds(L, slot + 1, &k_optimize<T, GROUP, PPL, FAST, 2>);
+        if (e != (int)hipSuccess) return e;
         hipLaunchKernelGGL((k_optimize<T, GROUP, PPL, FAST, 2>), grid, block, lds, s, a, kd);
         return (int)hipGetLastError();
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_optimize<T, GROUP, PPL, FAST>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerWorkgroup);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    int e = raise_dynamic_lds(L, slot, &k_optimize<T, GROUP, PPL, FAST>);
+    if (e != (int)hipSuccess) return e;
     hipLaunchKernelGGL((k_optimize<T, GROUP, PPL, FAST>), grid, block, lds, s, a, kd);
     return (int)hipGetLastError();
 }
 
 template <typename T, bool FAST>
-static int launch_optimize_p(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd) {
+static int launch_optimize_p(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, LaunchState& L) {
     // (one trajectory per wave for N <= 32 — 64 x 1 with half the lanes idle, no divergence between
     // the two line searches — measured slower: 0.462 vs 0.445 ms at B = 1024, 6.40 vs 3.60 ms at B = 16384)
     switch (shape_for(a.N)) {
         // (a 16-lane x 2-point shape saves one butterfly level but measured 22 % slower: 1.76 M vs 2.26 M/s)
-        case 0: return launch_optimize_t<T, 32, 1, FAST>(s, a, k, kd);
-        case 1: return launch_optimize_t<T, 64, 1, FAST>(s, a, k, kd);
-        case 2: return launch_optimize_t<T, 64, 2, FAST>(s, a, k, kd);
-        default: return launch_optimize_t<T, 64, 4, FAST>(s, a, k, kd);
+        case 0: return launch_optimize_t<T, 32, 1, FAST>(s, a, k, kd, L);
+        case 1: return launch_optimize_t<T, 64, 1, FAST>(s, a, k, kd, L);
+        case 2: return launch_optimize_t<T, 64, 2, FAST>(s, a, k, kd, L);
+        default: return launch_optimize_t<T, 64, 4, FAST>(s, a, k, kd, L);
     }
 }
 
-int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, int precision) {
+int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, int precision, LaunchState& L) {
     if (a.B <= 0) return hipSuccess;
-    if (precision == VIGO_PREC_F32) return launch_optimize_p<float, false>(s, a, k, kd);
-    if (precision == VIGO_PREC_F64_FAST) return launch_optimize_p<double, true>(s, a, k, kd);
-    return launch_optimize_p<double, false>(s, a, k, kd);
+    if (precision == VIGO_PREC_F32) return launch_optimize_p<float, false>(s, a, k, kd, L);
+    if (precision == VIGO_PREC_F64_FAST) return launch_optimize_p<double, true>(s, a, k, kd, L);
+    return launch_optimize_p<double, false>(s, a, k, kd, L);
 }
 
 // bytes of LDS one trajectory-solve workgroup needs; the C ABI refuses N it cannot hold

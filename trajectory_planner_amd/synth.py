@@ -239,3 +239,13 @@ def sphere_esdf(n: int, res: float, centre, radius: float):
     X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
     d = np.sqrt((X - centre[0]) ** 2 + (Y - centre[1]) ** 2 + (Z - centre[2]) ** 2) - radius
     return d.astype(np.float32), origin
+
+
+def edt_esdf(world: World):
+    """Config 5: fp32 signed distance field of a world's occupied voxels (bit2) by the exact Euclidean distance
+    transform (scipy), positive outside, negative inside, in metres; samples at voxel centres.  Returns
+    (float32 [nx,ny,nz], origin)."""
+    from scipy import ndimage
+    occ = (world.voxels & 4) != 0
+    d = (ndimage.distance_transform_edt(~occ) - ndimage.distance_transform_edt(occ)) * world.res
+    return np.ascontiguousarray(d.astype(np.float32)), np.array(world.origin, dtype=np.float64)

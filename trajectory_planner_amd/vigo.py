@@ -239,9 +239,22 @@ class Vigo:
     def optimize(self, ctrl, guide_off=None, guide_pv=None, guide_unk=None, obs_off=None, obs=None,
                  weights=None, inplace=False, out: Optional[SolveResult] = None) -> SolveResult:
         """vigo_optimize.  ctrl is cloned unless inplace=True (the C ABI updates it in place)."""
+        _shape(ctrl, (None, None, 3), "ctrl")
+        if ctrl.shape[1] < 7:
+            raise VigoError(f"vigo_optimize needs N >= 7 control points (got {ctrl.shape[1]}): VIGO_ERR_UNSUPPORTED_N")
         work = ctrl if inplace else ctrl.clone()
         B, N, pc, po, ppv, pu, poo, pob, ns, pw = self._solve_ptrs(work, guide_off, guide_pv, guide_unk,
                                                                     obs_off, obs, weights)
+        d = self.device
+        if out is not None:
+            # a caller-owned result is written by the kernel: wrong extents are out-of-range device writes
+            _shape(out.x, (B, N - 6, 3), "out.x")
+            for name in ("status", "iters", "evals", "fx"):
+                _shape(getattr(out, name), (B,), f"out.{name}")
+            _ptr(out.x, torch.float64, "out.x", d)
+            _ptr(out.fx, torch.float64, "out.fx", d)
+            for name in ("status", "iters", "evals"):
+                _ptr(getattr(out, name), torch.int32, f"out.{name}", d)
         if out is None:
             out = SolveResult(
                 ctrl=work,
@@ -350,6 +363,21 @@ class Vigo:
             (C.c_double * 3)(*box), float(map_res), C.c_void_p(flag.data_ptr()), C.c_void_p(first.data_ptr()),
             C.c_void_p(count.data_ptr())), "vigo_corridor_check")
         return flag, first, count
+
+    def poly_sample(self, coeffs, n_samp, delT, stride, want_f64=True, want_f32=False):
+        """vigo_poly_sample: positions of polyTrajSolver::getTrajectory for S segments ->
+        (pos f64 [S,stride,3] or None, pos f32 [S,stride,3] or None); rows k >= n_samp[s] are left untouched (zero)."""
+        _shape(coeffs, (None, 3, None), "coeffs")
+        S, _, d1 = coeffs.shape
+        _shape(n_samp, (S,), "n_samp")
+        _shape(delT, (S,), "delT")
+        p64 = torch.zeros(S, stride, 3, dtype=torch.float64, device=self.device) if want_f64 else None
+        p32 = torch.zeros(S, stride, 3, dtype=torch.float32, device=self.device) if want_f32 else None
+        self._check(self._lib.vigo_poly_sample(
+            self._h, S, d1 - 1, _ptr(coeffs, torch.float64, "coeffs", self.device),
+            _ptr(n_samp, torch.int32, "n_samp", self.device), _ptr(delT, torch.float64, "delT", self.device), int(stride),
+            C.c_void_p(p64.data_ptr()) if want_f64 else None, C.c_void_p(p32.data_ptr()) if want_f32 else None), "vigo_poly_sample")
+        return p64, p32
 
     def box_collision_points(self, pts, box, map_res):
         """vigo_box_collision_points: pts [M,3] f64 -> uint8 [M]"""
