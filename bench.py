@@ -16,7 +16,11 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
                streaming model, fp64, evaluated from the iteration/evaluation counts the kernel
                reports) / its average duration measured with HIP events on the launch stream;
                peak = 8 TB/s HBM3E.  traffic = HBM bytes per launch from rocprofv3 PMC
-               (profiles/*.json, when that summary exists for this workload) else null.
+               (profiles/pmc_<workload>_<precision>.json, when that summary exists) else null.
+               The kernel keeps its state in LDS/VGPRs, so the roofline that BINDS it is VALU issue:
+               issue_frac = SQ_INSTS_VALU x 4 cycles / (SIMDs x kernel cycles at the stated clock),
+               simd_occupancy = resident solver waves / SIMDs, measured_hbm_frac = traffic / kernel
+               time / peak — all three next to the streaming-model frac.
   cpu_baseline the CPU oracle (fp64 restatement, oracle/) timed on this box's host cores on a
                bounded sample of the same workload: kind "port", 1 thread (plus an all-core
                figure in cpu_baseline_allcores).
@@ -33,6 +37,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy rate
+SHADER_CLOCK_GHZ = 2.4  # MI355X peak engine clock (MI355X_MICROARCH.md); issue_frac is quoted against it
+VALU_ISSUE_CYCLES = 4   # a wave64 VALU instruction occupies its SIMD's issue port for 4 cycles (16 lanes per cycle)
 
 
 def parse():
@@ -88,7 +94,7 @@ def cpu_baseline(args, seconds, threads):
     world, batch, _ = workload(args, 0, 1)
     P = ol.default_params()
     P.max_iterations = args.iters
-    sub = min(batch.B, 256)
+    sub = min(batch.B, 1024)          # the batch itself (config 2), or its first 1024 trajectories
     from trajectory_planner_amd import synth
     piece = synth.Batch(batch.ctrl[:sub], np.ascontiguousarray(batch.guide_off[:sub * batch.N + 1]), batch.guide_pv,
                         batch.guide_unk)
@@ -174,67 +180,88 @@ def main():
     world, batch, wname = workload(args, rank, world_size)
     P = default_params()
     P.max_iterations = args.iters
-    v = Vigo(local_rank, P, {"f32": PREC_F32, "f64": PREC_F64, "f64_fast": 2}[args.precision])
+    prec_code = {"f32": PREC_F32, "f64": PREC_F64, "f64_fast": 2}
+    v = Vigo(local_rank, P, prec_code[args.precision])
     v.use_current_stream()
-
-    # ---- voxel snapshot: rank 0 packs, one RCCL broadcast over xGMI, every rank adopts it ----
-    dims = world.voxels.shape
-    nwords = v._lib.vigo_grid_packed_bytes(*dims) // 4
-    t_b0 = time.perf_counter()
-    if rank == 0:
-        packed = v.pack_grid(torch.from_numpy(world.voxels).to(dev))
-    else:
-        packed = torch.empty(nwords, dtype=torch.int32, device=dev)
-    bcast_ms = 0.0
-    if world_size > 1:
-        torch.cuda.synchronize()
-        dist.barrier()
-        t_b0 = time.perf_counter()
-        bcast(packed)
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - t_b0) * 1e3
-    v.set_grid_packed(packed, dims, world.origin, world.res)
-
+    from trajectory_planner_amd.vigo import SolveResult
     T = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    ctrl0, goff, gpv = T(batch.ctrl), T(batch.guide_off), T(batch.guide_pv)
-    work = ctrl0.clone()
+
+    def install_map(vv, world_):
+        """voxel snapshot: rank 0 packs, ONE RCCL broadcast over xGMI, every rank adopts it; returns (packed, ms)"""
+        dims_ = world_.voxels.shape
+        nwords = vv._lib.vigo_grid_packed_bytes(*dims_) // 4
+        if rank == 0:
+            packed_ = vv.pack_grid(torch.from_numpy(world_.voxels).to(dev))
+        else:
+            packed_ = torch.empty(nwords, dtype=torch.int32, device=dev)
+        ms = 0.0
+        if world_size > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_b0 = time.perf_counter()
+            bcast(packed_)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t_b0) * 1e3
+        vv.set_grid_packed(packed_, dims_, world_.origin, world_.res)
+        return packed_, ms
+
+    def timed_solves(vv, batch_, steps, warmup):
+        """`steps` passes of the hot path over a resident batch (restore the control points D2D, isUnknown of the
+        guide points, the whole solve in one launch), barrier + synchronize on both sides, MAX over ranks;
+        HIP events around the solve launch on its stream.  Returns (elapsed s, kernel ms, SolveResult, buffers)."""
+        ctrl0_, goff_, gpv_ = T(batch_.ctrl), T(batch_.guide_off), T(batch_.guide_pv)
+        work_ = ctrl0_.clone()
+        B_, N_ = batch_.B, batch_.N
+        res_ = SolveResult(work_, torch.empty(B_, N_ - 6, 3, dtype=torch.float64, device=dev),
+                           torch.empty(B_, dtype=torch.int32, device=dev), torch.empty(B_, dtype=torch.float64, device=dev),
+                           torch.empty(B_, dtype=torch.int32, device=dev), torch.empty(B_, dtype=torch.int32, device=dev))
+        e0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        e1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+
+        def one(i=None):
+            work_.copy_(ctrl0_)
+            gunk = vv.guides_unknown(gpv_) if gpv_.shape[0] else None
+            if i is not None:
+                e0[i].record()
+            vv.optimize(work_, goff_, gpv_ if gpv_.shape[0] else None, gunk, inplace=True, out=res_)
+            if i is not None:
+                e1[i].record()
+
+        for _ in range(warmup):
+            one()
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+        t_0 = time.perf_counter()
+        for i in range(steps):
+            one(i)
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+        el = time.perf_counter() - t_0
+        if world_size > 1:
+            el = max_over_ranks(el)
+        return el, float(np.mean([x.elapsed_time(y) for x, y in zip(e0, e1)])), res_, (ctrl0_, goff_, gpv_, work_, one)
+
+    packed, bcast_ms = install_map(v, world)
+    dims = world.voxels.shape
+    snapshot_ok = None
+    if world_size > 1:
+        # every rank answers the same seeded point queries from the snapshot it adopted; the answers must agree
+        qp = T(np.random.default_rng(99).uniform(world.origin.min() - 0.5, -world.origin.min() + 0.5, size=(4096, 3)))
+        sig = torch.stack([v.query_points(qp, w).to(torch.float64) @ torch.arange(1, 4097, dtype=torch.float64, device=dev)
+                           for w in (0, 1)]).cpu()
+        lo, hi = sig.clone(), sig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        snapshot_ok = bool(torch.equal(lo, hi) and float(sig.sum()) > 0)
     B, N = batch.B, batch.N
     n = 3 * (N - 6)
-    from trajectory_planner_amd.vigo import SolveResult
-    res = SolveResult(work, torch.empty(B, N - 6, 3, dtype=torch.float64, device=dev),
-                      torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.float64, device=dev),
-                      torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev))
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-
-    def step(i=None):
-        work.copy_(ctrl0)
-        gunk = v.guides_unknown(gpv) if gpv.shape[0] else None
-        if i is not None:
-            ev0[i].record()
-        v.optimize(work, goff, gpv if gpv.shape[0] else None, gunk, inplace=True, out=res)
-        if i is not None:
-            ev1[i].record()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world_size > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world_size > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world_size > 1:
-        elapsed = max_over_ranks(elapsed)
-
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    elapsed, kern_ms, res, (ctrl0, goff, gpv, work, step) = timed_solves(v, batch, args.steps, args.warmup)
     iters = res.iters.cpu().numpy()      # of the timed configuration (the side measurements below overwrite res)
     evals = res.evals.cpu().numpy()
 
+    simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
     # ---- side measurements (outside the timed region above; rank 0 of a single-GPU run only) ----
     extra = {}
     if rank == 0 and world_size == 1 and not args.no_extras:
@@ -331,6 +358,31 @@ def main():
                                           "note": "independent batches alternating over two HIP streams; never `value`"}
         for _, vv, _, _ in lanes:
             vv.close()
+        # (e) the same build on a batch that fills the chip: 16 384 x 32 on the same map (8192 waves on 1024 SIMDs)
+        if args.workload == "config2":
+            from trajectory_planner_amd import synth
+            big = synth.make_bspline_batch(world, 16384, 32, synth.SEED_BASE + 2 + 5000)
+            el, kms, r_big, _ = timed_solves(v, big, max(5, args.steps // 20), 2)
+            extra["config2_at_16384"] = {"value": 16384 * max(5, args.steps // 20) / el, "unit": "trajectories/s", "kernel_ms": kms,
+                                         "simd_occupancy": min(1.0, (16384 // 2) / simds), "note": "same map, B = 16384 x 32; never `value`"}
+            del big, r_big
+    # (f) one GPU's shard of BASELINE configs[3] (8192 x 64 control points, 512^3 map) on every rank count, so the
+    #     1 -> 8 record covers the configuration BASELINE names for 8 GPUs; never `value`
+    if args.workload == "config2" and not args.no_extras:
+        args4 = argparse.Namespace(**vars(args))
+        args4.workload, args4.batch = "config4", 0
+        world4, batch4, name4 = workload(args4, rank, world_size)
+        v4 = Vigo(local_rank, P, prec_code[args.precision])
+        v4.use_current_stream()
+        _, bcast4_ms = install_map(v4, world4)
+        k4 = max(5, args.steps // 20)
+        el4, kms4, r4, _ = timed_solves(v4, batch4, k4, 2)
+        extra["config4_shard"] = {"workload": name4, "value": batch4.B * world_size * k4 / el4, "unit": "trajectories/s", "n_gpus": world_size,
+                                  "ms_per_step": el4 / k4 * 1e3, "kernel_ms": kms4, "map_bcast_ms": bcast4_ms, "steps": k4,
+                                  "simd_occupancy": min(1.0, batch4.B / simds), "mean_iters": float(r4.iters.float().mean().item()),
+                                  "note": "whole-job aggregate over all ranks (max-over-ranks time); never `value`"}
+        v4.close()
+        del world4, batch4, r4
     gp = np.diff(batch.guide_off).reshape(B, N).sum(1)
     elem = 4 if args.precision == "f32" else 8
     alg_bytes = float(algorithmic_bytes(n, P.mem_size, iters, evals, gp, elem).sum())
@@ -339,13 +391,43 @@ def main():
     if rank == 0:
         total = B * world_size * args.steps
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", f"pmc_{args.workload}_{args.precision}.json")
-        if os.path.exists(pmc):
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.workload}_{args.precision}.json")
+        if os.path.exists(pmc_path) and not args.batch:
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_path))
+                traffic = pmc.get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                pmc, traffic = {}, None
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        tpb = 2 if N <= 32 else 1                       # trajectories per solver wavefront (vigo_solver.hip)
+        waves = (B + tpb - 1) // tpb
+        kernel_cycles = kern_ms * 1e-3 * SHADER_CLOCK_GHZ * 1e9
+        cnt = pmc.get("counters_per_launch", {})
+        valu = cnt.get("SQ_INSTS_VALU")
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "vigo::k_optimize", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "byte_model": "SURVEY.md §8(d) streaming model x fp64 (state streamed per BLAS-1 pass, as the CPU "
+                              "reference does); the kernel keeps that state in LDS/VGPRs, so HBM sees only the "
+                              "compulsory bytes below and `frac` is a model figure, not what binds the kernel",
+                "compulsory_bytes_per_launch": compulsory,
+                "compulsory_frac": compulsory / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                # the roofline that binds: VALU issue.  One wave64 VALU instruction holds its SIMD's issue port for
+                # 4 cycles, so the chip retires at most SIMDs / 4 wave-instructions per cycle.
+                "binding": "valu_issue",
+                "simds": simds, "waves_per_launch": waves, "simd_occupancy": min(1.0, waves / simds),
+                "shader_clock_ghz": SHADER_CLOCK_GHZ,
+                "issue_frac": (valu * VALU_ISSUE_CYCLES / (simds * kernel_cycles)) if valu else None,
+                "issue_frac_of_occupied_simds": (valu * VALU_ISSUE_CYCLES / (min(waves, simds) * kernel_cycles)) if valu else None,
+                "valu_insts_per_wave": (valu / cnt["SQ_WAVES"]) if valu and cnt.get("SQ_WAVES") else None,
+                "measured_hbm_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "pmc_source": (os.path.relpath(pmc_path, ROOT) + " (" + str(pmc.get("build", "build not recorded")) + ")") if pmc else None}
+        if cnt.get("SQ_ACTIVE_INST_VALU") and cnt.get("SQ_WAVE_CYCLES"):
+            # share of the waves' lifetime during which a VALU instruction of theirs was executing
+            roof["valu_busy_of_wave_lifetime"] = cnt["SQ_ACTIVE_INST_VALU"] / cnt["SQ_WAVE_CYCLES"]
+        if cnt.get("SQ_WAIT_INST_ANY") and cnt.get("SQ_WAVE_CYCLES"):
+            roof["memory_wait_of_wave_lifetime"] = cnt["SQ_WAIT_INST_ANY"] / cnt["SQ_WAVE_CYCLES"]
         out = {
             "metric": "B-spline trajs/s (32 ctrl pts, 256^3 grid, 50 iters) @1 GPU; % HBM roofline"
             if args.workload == "config2" else "B-spline trajs/s (64 ctrl pts, 512^3 grid, 50 iters)",
@@ -367,23 +449,17 @@ def main():
                        "guide_pairs_per_gpu": int(gpv.shape[0]), "sharding": f"batch-dp{world_size}, no data-path collective",
                        "mean_iters": float(iters.mean()), "mean_evals": float(evals.mean())},
             "map_bcast_ms": bcast_ms,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "vigo::k_optimize", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "byte_model": "SURVEY.md §8(d) streaming model x fp64 (state streamed per BLAS-1 pass, as the CPU "
-                                       "reference does); the kernel keeps that state in LDS/VGPRs, so HBM sees only the "
-                                       "compulsory bytes below",
-                         "limiter": "instruction issue of one wavefront per SIMD (VALU busy 61 %, memory waits 2 %: "
-                                    "profiles/README.md); the HBM fraction above is the SURVEY's streaming model, not what the "
-                                    "kernel is bound by",
-                         "compulsory_bytes_per_launch": compulsory,
-                         "compulsory_frac": compulsory / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "map_snapshot_identical_on_all_ranks": snapshot_ok,
+            "roofline": roof,
         }
         out.update(extra)
         if cpu is not None:
             out["cpu_baseline"] = {"value": cpu["single"], "unit": "trajectories/s", "cores": 1, "kind": "port",
-                                   "sample": f"{cpu['single_n']} solves: repeats of the first 256 trajectories of the same "
-                                             f"batch, oracle/vigo_oracle.c (fp64, reference order) on 1 host thread"}
+                                   "sample": f"{cpu['single_n']} solves: repeats of the batch itself (its first 1024 trajectories), "
+                                             f"oracle/vigo_oracle.c (fp64, reference order, gcc -O3) on 1 host thread.  Caveat: the port "
+                                             f"does not make the reference's five 3xN heap allocations per evaluation "
+                                             f"(bsplineTraj.cpp:807-810,817) nor its per-call L-BFGS mallocs (lbfgs.hpp:1107-1123), so it "
+                                             f"is a slightly optimistic stand-in for the reference's optimize()"}
             out["cpu_baseline_allcores"] = {"value": cpu["all"], "unit": "trajectories/s", "cores": cpu["threads"],
                                             "kind": "port", "sample": f"{cpu['all_n']} solves, one process per host core"}
         print(json.dumps(out))

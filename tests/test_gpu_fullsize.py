@@ -74,19 +74,26 @@ def test_sampler_positions_bit_exact_on_a_million_pairs(vigo_handle):
     coeffs, n_samp, delT, dur = synth.make_corridor_segments(77, S, extent_lo=(-15.0, -15.0, 0.2), extent_hi=(3.5, 2.5, 2.2), n_samples=NS)
     delT[:16] = 0.1 / 16                                   # the reference's sample_delta_time scale, long clocks
     coeffs[16:24] *= 37.0                                  # larger magnitudes
+    # strongly cancelling terms (|x| << sum |c_d| t^d around the zero crossing): the float filter of the kernels cannot
+    # certify many of these samples and falls back to the exact-power chain
+    coeffs[24:32, :, 0] = 3000.0
+    coeffs[24:32, :, 1] = -6000.0 / dur[24:32, None]
+    coeffs[32:34, 0, 3] = np.inf                           # non-finite coefficients: nothing certifies
+    coeffs[34:36, 1, 2] = np.nan
     p64, p32 = v.poly_sample(to_dev(coeffs, v.device), to_dev(n_samp, v.device), to_dev(delT, v.device), NS, want_f64=True, want_f32=True)
     p64, p32 = p64.cpu().numpy(), p32.cpu().numpy()
     with ol.pow_mode(True):
         ref = ol.poly_sample(coeffs, n_samp, delT, NS)
-    assert np.array_equal(p64, ref)
-    assert np.array_equal(p32, ref.astype(np.float32))
+    assert np.array_equal(p64, ref, equal_nan=True)
+    assert np.array_equal(p32, ref.astype(np.float32), equal_nan=True)
     with ol.pow_mode(False):
         ref_libm = ol.poly_sample(coeffs, n_samp, delT, NS)
-    differ = (ref_libm != ref).any(axis=2).mean()
+    fin = np.isfinite(ref).all(axis=2)
+    differ = (ref_libm != ref).any(axis=2)[fin].mean()
     print(f"\nsampler: {S * NS} positions bit-identical to the exact-pow oracle; libm-pow positions differ in the last bit for "
           f"{differ * 100:.3f} % of them (glibc's own rounding)")
     assert differ < 0.05
-    assert np.array_equal(p32, ref_libm.astype(np.float32))
+    assert np.array_equal(p32, ref_libm.astype(np.float32), equal_nan=True)
     # other degrees go through the generic path
     for deg in (3, 9, 15):
         c2, n2, t2, _ = synth.make_corridor_segments(80 + deg, 16, deg=deg, n_samples=2048)
@@ -112,8 +119,9 @@ def test_config5_esdf_queries_at_full_size(vigo_handle):
     order = np.lexsort((brick[:, 2], brick[:, 1], brick[:, 0]))
     ds, gs = v.esdf_query(to_dev(pts[order], v.device))
     assert np.array_equal(ds.cpu().numpy(), d_ref[order]) and np.array_equal(gs.cpu().numpy(), g_ref[order])
-    inside = (np.abs(pts) < 12.0).all(1)
-    assert np.isfinite(d_ref).all() and (np.linalg.norm(g_ref[inside], axis=1) < 1.8).all()
+    assert np.isfinite(d_ref).all() and np.isfinite(g_ref).all()
+    far = d_ref > 1.0                                    # away from the surfaces the EDT is smooth: |grad| ~ 1
+    assert abs(np.median(np.linalg.norm(g_ref[far], axis=1)) - 1.0) < 0.05
 
 
 def test_config5_dynamic_obstacle_term_at_full_size(vigo_handle):

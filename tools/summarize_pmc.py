@@ -66,6 +66,7 @@ def main():
     fetch_kib = merged.get("FETCH_SIZE", (0.0, 0))[0]
     write_kib = merged.get("WRITE_SIZE", (0.0, 0))[0]
     res = {
+        "build": os.environ.get("VIGO_BUILD", "unrecorded"),   # commit the profiled library was built from (set by the caller)
         "source": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python bench.py (see profiles/README.md); "
                   f"averages over the dispatches of the kernel matching '{kernel}'",
         "dispatches": {k: n for k, (_, n) in merged.items()},

@@ -13,6 +13,8 @@
 //           every lattice point of the box sweep up in the LDS tile (a segment makes ~10^5
 //           lookups inside a few thousand words).
 // A tile too large for the LDS budget falls back to lookups in the packed planes (L2).
+#include <type_traits>
+
 #include "vigo_exact_pow.hpp"
 #include "vigo_exact_time.hpp"
 #include "vigo_grid.hpp"
@@ -23,6 +25,7 @@ namespace {
 constexpr int kChunk = 16;       // consecutive samples per thread visit
 constexpr int kBlock = 256;
 constexpr int kMaxDeg = 15;
+constexpr int kQueueCap = 1024;   // LDS queue of samples for the exact-power pass of k_corridor
 
 // collision_box / map_resolution of the sweep and octomap's resolution_factor (1 / tree resolution)
 struct SweepConst {
@@ -97,6 +100,80 @@ __device__ __forceinline__ void poly_pos7(const double (&c7)[3][8], double t, do
         z += c7[2][d] * pw[d];
     }
     p[0] = x; p[1] = y; p[2] = z;
+}
+
+// ---- the float position the checker consumes (pose2Octomap, PO.cpp:634-656), by a floating-point filter ----
+// The box sweep sees (float)x, (float)y, (float)z only.  Evaluating the exact-power chain above for every sample
+// costs 30 % of the whole checker (0.685 -> 0.895 ms on config 3), so the kernels use the classical
+// filtered-predicate scheme instead:
+//   fast   the same sums with the powers formed by repeated multiplication (1 instead of ~10 operations per power);
+//   bound  |fast - exact chain| <= (3 deg + 2) u A with u = 2^-53 and A = sum_d |c_d| T^d >= every partial sum and
+//          term (T = the largest sampled |t|): d u |c_d t^d| from the power, 2 u |c_d t^d| from the two roundings of
+//          the product, 2 u A per addition.  E = 2^-46 A + 2^-1000 (= 128 u A, more than twice the bound for
+//          deg <= 15, plus the absolute error of a gradual underflow) is computed once per segment and axis;
+//   filter the conversion to float is monotone, so (float)(fast - E) == (float)(fast + E) certifies that value as the
+//          float of the exact chain.  A sample that cannot certify all three axes (probability ~2^-21 A / |x| per
+//          axis, or a NaN / overflow anywhere) is re-evaluated with the exact chain: k_corridor queues its index in
+//          LDS and sweeps the queue after the main pass, so the rare path costs the main loop no registers.
+// Results are therefore those of the exact-power chain by construction.
+__device__ __forceinline__ double sampler_error_bound(const double* c, int deg, double t_last) {
+    const double T = fabs(t_last);
+    double A = 0.0, pw = 1.0;
+    for (int d = 0; d <= deg; ++d) {
+        A += fabs(c[d]) * pw;
+        pw *= T;
+    }
+    return 0x1p-46 * A + 0x1p-1000;   // inf / NaN for such coefficients or clocks: nothing certifies, every sample is exact
+}
+
+__device__ __forceinline__ void poly_fast7(const double (&c7)[3][8], double t, double (&p)[3]) {
+    double x = 0, y = 0, z = 0, pw = 1.0;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        x += c7[0][d] * pw;
+        y += c7[1][d] * pw;
+        z += c7[2][d] * pw;
+        pw *= t;
+    }
+    p[0] = x; p[1] = y; p[2] = z;
+}
+__device__ __forceinline__ void poly_fast(const double* cf, int deg, double t, double (&p)[3]) {
+    double x = 0, y = 0, z = 0, pw = 1.0;
+    for (int d = 0; d <= deg; ++d) {
+        x += cf[d] * pw;
+        y += cf[(kMaxDeg + 1) + d] * pw;
+        z += cf[2 * (kMaxDeg + 1) + d] * pw;
+        pw *= t;
+    }
+    p[0] = x; p[1] = y; p[2] = z;
+}
+
+__device__ __forceinline__ double uniform_f64(double v) {   // a wave-uniform value through SGPRs
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// fast form + filter: true when f holds the certified floats of the exact chain
+template <bool DEG7>
+__device__ __forceinline__ bool sample_f32_fast(const double (&c7)[3][8], const double* cf, int deg, double t,
+                                                const double (&E)[3], float (&f)[3]) {
+    double p[3];
+    if (DEG7) poly_fast7(c7, t, p);
+    else poly_fast(cf, deg, t, p);
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float lo = (float)(p[a] - E[a]), hi = (float)(p[a] + E[a]);
+        f[a] = lo;
+        ok = ok && (lo == hi);            // false for NaN
+    }
+    return ok;
+}
+// the exact-power chain itself (coefficients from LDS: this path is rare and must not cost the fast one registers)
+__device__ __noinline__ void sample_f32_exact(const double* cf, int deg, double t, float (&f)[3]) {
+    double p[3];
+    poly_pos(cf, deg, t, p);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) f[a] = (float)p[a];
 }
 
 // order-preserving float <-> int for LDS atomic min/max
@@ -222,11 +299,14 @@ __device__ __forceinline__ bool box_sweep(const GridView& g, const SweepConst& C
     return hit;
 }
 
-__global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A) {
+// (four waves per SIMD = at most 128 VGPRs: the filter left the allocation at 129)
+__global__ void __launch_bounds__(kBlock, 4) k_corridor(GridView g, CorridorArgs A) {
     extern __shared__ __align__(16) uint32_t tile_words[];
     __shared__ double cf[3 * (kMaxDeg + 1)];
     __shared__ int s_min[3], s_max[3];
+    __shared__ double s_err[3];
     __shared__ int s_first, s_count;
+    __shared__ int q_n, q_idx[kQueueCap];          // samples the float filter could not certify
 
     const int s = blockIdx.x;
     if (s >= A.S) return;
@@ -240,7 +320,7 @@ __global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A)
         cf[ax * (kMaxDeg + 1) + d] = A.coeffs[((size_t)s * 3 + ax) * (deg + 1) + d];
     }
     if (tid < 3) { s_min[tid] = 0x7fffffff; s_max[tid] = (int)0x80000000; }
-    if (tid == 0) { s_first = 0x7fffffff; s_count = 0; }
+    if (tid == 0) { s_first = 0x7fffffff; s_count = 0; q_n = 0; }
     __syncthreads();
 
     const int n_chunks = (n + kChunk - 1) / kChunk;
@@ -250,9 +330,11 @@ __global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A)
     //      instead of a pass over all samples.  The bound only sizes the LDS tile: a pose whose
     //      lattice points fall outside the tile takes the L2 path in box_sweep, so results never
     //      depend on it. ----
+    if (tid < 3) s_err[tid] = 0.0;
     if (tid < 3 && n > 0) {
         const double tl = accumulated_time(dT, n - 1);        // clock value of the last sample
         const double* c = cf + tid * (kMaxDeg + 1);
+        s_err[tid] = sampler_error_bound(c, deg, tl);         // filter of sample_f32()
         double lo = c[0], hi = c[0];                           // b_0 = c_0
         // b_i = sum_{k <= i} C(i,k) / C(deg,k) * c_k * tl^k
         for (int i = 1; i <= deg; ++i) {
@@ -318,32 +400,61 @@ __global__ void __launch_bounds__(kBlock) k_corridor(GridView g, CorridorArgs A)
     memo.verdict = false;
 #pragma unroll
     for (int i = 0; i < kAxisMax; ++i) memo.kx[i] = memo.ky[i] = memo.kz[i] = 0;
-    auto walk = [&](auto eval) {
-        for (int c = tid; c < n_chunks; c += kBlock) {
-            const int k0 = c * kChunk, k1 = min(n, k0 + kChunk);
-            double t = accumulated_time(dT, k0);
-            for (int k = k0; k < k1; ++k) {
-                double p[3];
-                eval(t, p);
-                const float fx = (float)p[0], fy = (float)p[1], fz = (float)p[2];  // pose2Octomap
-                const bool hit = box_sweep(g, A.sweep, fx, fy, fz, &T, tile_words, &memo);
-                if (hit) {
-                    if (k < my_first) my_first = k;
-                    ++my_count;
-                }
-                t += dT;
-            }
-        }
-    };
-    if (deg == 7) {
+    // (block-uniform: kept in SGPRs — six VGPRs more would cost the kernel its fourth wave per SIMD)
+    const double E[3] = {uniform_f64(s_err[0]), uniform_f64(s_err[1]), uniform_f64(s_err[2])};
+    {
+        // the planner's degree (cfg polynomial_degree: 7) keeps its coefficients in registers
         double c7[3][8];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int d = 0; d < 8; ++d) c7[a][d] = cf[a * (kMaxDeg + 1) + d];
-        walk([&](double t, double (&p)[3]) { poly_pos7(c7, t, p); });
-    } else {
-        walk([&](double t, double (&p)[3]) { poly_pos(cf, deg, t, p); });
+            for (int d = 0; d < 8; ++d) c7[a][d] = deg == 7 ? cf[a * (kMaxDeg + 1) + d] : 0.0;
+        auto walk = [&](auto deg7_tag) {
+            constexpr bool DEG7 = decltype(deg7_tag)::value;
+            for (int c = tid; c < n_chunks; c += kBlock) {
+                const int k0 = c * kChunk, k1 = min(n, k0 + kChunk);
+                double t = accumulated_time(dT, k0);
+                for (int k = k0; k < k1; ++k) {
+                    float f[3];
+                    if (sample_f32_fast<DEG7>(c7, cf, deg, t, E, f)) {    // pose2Octomap of getPose(t), certified
+                        if (box_sweep(g, A.sweep, f[0], f[1], f[2], &T, tile_words, &memo)) {
+                            if (k < my_first) my_first = k;
+                            ++my_count;
+                        }
+                    } else {
+                        const int slot = atomicAdd(&q_n, 1);               // (q_n counts past the capacity: see below)
+                        if (slot < kQueueCap) q_idx[slot] = k;
+                    }
+                    t += dT;
+                }
+            }
+        };
+        if (deg == 7) walk(std::true_type{});
+        else walk(std::false_type{});
+    }
+    __syncthreads();
+    // ---- the queued samples, with the exact-power chain.  A queue that overflowed (non-finite coefficients, a
+    //      polynomial that cancels to ~0 over its whole span) is replaced by a walk over all samples that repeats
+    //      the filter and handles exactly those it rejects — the same set. ----
+    {
+        const int queued = q_n;
+        auto exact_one = [&](int k) {
+            float f[3];
+            sample_f32_exact(cf, deg, accumulated_time(dT, k), f);
+            if (box_sweep(g, A.sweep, f[0], f[1], f[2], &T, tile_words, nullptr)) {
+                if (k < my_first) my_first = k;
+                ++my_count;
+            }
+        };
+        if (queued <= kQueueCap) {
+            for (int i = tid; i < queued; i += kBlock) exact_one(q_idx[i]);
+        } else {
+            const double c0[3][8] = {};
+            for (int k = tid; k < n; k += kBlock) {
+                float f[3];
+                if (!sample_f32_fast<false>(c0, cf, deg, accumulated_time(dT, k), E, f)) exact_one(k);
+            }
+        }
     }
     if (my_count) {
         atomicMin(&s_first, my_first);
@@ -379,17 +490,32 @@ __global__ void __launch_bounds__(kBlock) k_poly_sample(int S, int deg, const do
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int d = 0; d < 8; ++d) c7[a][d] = deg == 7 ? cf[a * (kMaxDeg + 1) + d] : 0.0;
+    // the float output takes the checker's own route (filtered fast form, sample_f32); the fp64 output is the
+    // exact-power chain itself
+    double E[3] = {0.0, 0.0, 0.0};
+    if (n > 0) {
+        const double tl = accumulated_time(dT, n - 1);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) E[a] = sampler_error_bound(cf + a * (kMaxDeg + 1), deg, tl);
+    }
     const int n_chunks = (n + kChunk - 1) / kChunk;
     for (int c = tid; c < n_chunks; c += kBlock) {
         const int k0 = c * kChunk, k1 = min(n, k0 + kChunk);
         double t = accumulated_time(dT, k0);
         for (int k = k0; k < k1; ++k) {
-            double p[3];
-            if (deg == 7) poly_pos7(c7, t, p);
-            else poly_pos(cf, deg, t, p);
             const size_t o = ((size_t)s * stride + k) * 3;
-            if (out_pos) { out_pos[o] = p[0]; out_pos[o + 1] = p[1]; out_pos[o + 2] = p[2]; }
-            if (out_f32) { out_f32[o] = (float)p[0]; out_f32[o + 1] = (float)p[1]; out_f32[o + 2] = (float)p[2]; }   // pose2Octomap
+            if (out_pos) {
+                double p[3];
+                if (deg == 7) poly_pos7(c7, t, p);
+                else poly_pos(cf, deg, t, p);
+                out_pos[o] = p[0]; out_pos[o + 1] = p[1]; out_pos[o + 2] = p[2];
+            }
+            if (out_f32) {
+                float f[3];
+                const bool ok = deg == 7 ? sample_f32_fast<true>(c7, cf, deg, t, E, f) : sample_f32_fast<false>(c7, cf, deg, t, E, f);
+                if (!ok) sample_f32_exact(cf, deg, t, f);
+                out_f32[o] = f[0]; out_f32[o + 1] = f[1]; out_f32[o + 2] = f[2];
+            }
             t += dT;
         }
     }
