@@ -81,7 +81,7 @@ typedef enum {
  * vigo_default_params() loads cfg/bspline_interactive/bspline_planner_param.yaml values and
  * the solver settings of BT.cpp:695-699 / LB:942-954.
  */
-typedef struct {
+typedef struct vigo_params_s {
     /* cost terms */
     double dthresh;              /* dthresh_               BT.cpp:35   */
     double dist_thresh_dynamic;  /* distThreshDynamic_     BT.cpp:143  */
@@ -261,6 +261,55 @@ int vigo_traj_dynamic_collision(vigo_handle_t h, int B, int N, const double* ctr
  */
 int vigo_ctrl_occupancy(vigo_handle_t h, int B, int N, const double* ctrl,
                         uint8_t* out_pt, uint8_t* out_line);
+
+/* ---- the rebound loop between two A* calls, device-resident ------------------------------ */
+
+/*
+ * Replaces: the while loop of bsplineTraj::optimizeTrajectory (BT.cpp:611-685) for B trajectories, for as long as
+ * a trajectory needs nothing from the host.  One round per trajectory =
+ *     hasCollisionTrajectory / hasDynamicCollisionTrajectory     (BT.cpp:620-626, BT.h:307-368; the dynamic gate
+ *                                                                  only when the trajectory has obstacles)
+ *     neither          -> VIGO_RB_DONE                            (BT.cpp:628-631)
+ *     failCount >= 4   -> VIGO_RB_NEEDS_HOST                      (forced A* re-guide, BT.cpp:640-654)
+ *     static collision -> isReguideRequired (BT.cpp:573-608: findCollisionSeg :403-445 on the new control points,
+ *                         comparison with the previous segments, isControlPointRequireNewGuide BT.h:417-429):
+ *                         required -> VIGO_RB_NEEDS_HOST (A*, BT.cpp:656-665; nothing of the state is touched, the
+ *                         host repeats the step itself); else collisionSeg_ := the new segments,
+ *                         weightDistance *= 2, ++failCount      (BT.cpp:666-674)
+ *     dynamic collision -> weightDynamicObstacle *= 2             (BT.cpp:677-679)
+ *     optimize()                                                  (BT.cpp:680, = vigo_optimize on the still-active set,
+ *                                                                  compacted on the device)
+ * max_rounds rounds are queued without a host round trip; trajectories that are done or wait for the host are
+ * skipped, and once a round hands a trajectory to the host the rest of the call is a no-op for the whole batch: the
+ * optimize() the still-active trajectories owe is left to the next call (their solve_first is set), where it shares
+ * one launch with the re-guided ones — the waiting trajectories are on the batch's critical path.  A trajectory whose state has solve_first != 0 is optimized once before its first gate (the
+ * optimize() of BT.cpp:612, or the one that follows a host-side re-guide).
+ *   ctrl, guide_*, obs_*       as vigo_optimize (guide_unk from vigo_guides_unknown); ctrl in/out
+ *   weights   double[B][4]     in/out, REQUIRED (the loop doubles them per trajectory)
+ *   gate_dt                    sample step of the gates, map_->getRes() / maxVel_ / 2 (BT.h:312)
+ *   not_check_ratio            notCheckRatio_ of findCollisionSeg (BT.cpp:408; 0 in the reference)
+ *   state     vigo_rebound_state_t[B] in/out (device memory)
+ * Needs vigo_set_grid.  The 30 ms wall-clock budget of BT.cpp:633 stays with the caller (between calls).
+ */
+enum { VIGO_MAX_COLLISION_SEGS = 48 };
+typedef enum { VIGO_RB_ACTIVE = 0, VIGO_RB_DONE = 1, VIGO_RB_NEEDS_HOST = 2 } vigo_rebound_status_t;
+typedef struct {
+    int32_t status;        /* vigo_rebound_status_t; only VIGO_RB_ACTIVE entries are worked on      */
+    int32_t solve_first;   /* in: optimize before the first gate; out: an optimize() is still owed    */
+    int32_t fail_count;    /* failCount, BT.cpp:613                                                 */
+    int32_t gate_static;   /* out: last hasCollisionTrajectory result                               */
+    int32_t gate_dynamic;  /* out: last hasDynamicCollisionTrajectory result                        */
+    int32_t rounds;        /* out: += gate passes made by the call                                  */
+    int32_t lbfgs_status;  /* out: lbfgs_optimize return code of the last optimize() (LB:20-80)     */
+    int32_t n_seg;         /* collisionSeg_ (BT.h:73) as isReguideRequired left it: n_seg pairs     */
+    int32_t seg[2 * VIGO_MAX_COLLISION_SEGS];   /* (first, second); more segments than fit -> NEEDS_HOST */
+} vigo_rebound_state_t;
+
+int vigo_rebound_rounds(vigo_handle_t h, int B, int N, double* ctrl,
+                        const int32_t* guide_off, const double* guide_pv, const uint8_t* guide_unk,
+                        const int32_t* obs_off, const double* obs, int n_obs_shared,
+                        double* weights, double gate_dt, double not_check_ratio, int max_rounds,
+                        vigo_rebound_state_t* state);
 
 /* ---- min-snap QP and corridor collision checker ------------------------------------ */
 

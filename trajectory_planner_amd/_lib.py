@@ -73,6 +73,7 @@ PROTOTYPES = {
     "vigo_check_lists": (_i, [_vp, _i, _i, _vp, _i64, _vp, _i64]),
     "vigo_cost_grad": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "vigo_optimize": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vigo_rebound_rounds": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _d, _d, _i, _vp]),
     "vigo_bspline_fit": (_i, [_vp, _i, _i, _d, _vp, _vp, _vp]),
     "vigo_bspline_eval": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "vigo_traj_collision": (_i, [_vp, _i, _i, _vp, _d, _vp, _vp]),

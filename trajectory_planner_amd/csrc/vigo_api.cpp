@@ -253,6 +253,7 @@ int vigo_destroy(vigo_handle_t h) {
     if (h->fit_pinvT) (void)hipFree(h->fit_pinvT);
     if (h->times_dev) (void)hipFree(h->times_dev);
     if (h->scratch) (void)hipFree(h->scratch);
+    if (h->rebound_idx) (void)hipFree(h->rebound_idx);
     if (h->dc_dev) (void)hipFree(h->dc_dev);
     for (int i = 0; i < vigo_context::kDcSlots; ++i)
         if (h->dc_event[i]) (void)hipEventDestroy(h->dc_event[i]);
@@ -455,6 +456,64 @@ int vigo_optimize(vigo_handle_t h, int B, int N, double* ctrl, const int32_t* gu
     if (vigo::optimize_lds_requirement(N, h->params.mem_size, h->precision) > (size_t)160 * 1024)
         return fail(h, VIGO_ERR_UNSUPPORTED_N, "the L-BFGS history of N control points x mem_size does not fit the 160 KiB LDS of a CU");
     VIGO_HIP(h, (hipError_t)vigo::launch_optimize(h->stream, a, h->dc, h->dc_dev, h->precision, h->launch));
+    return VIGO_OK;
+}
+
+int vigo_rebound_rounds(vigo_handle_t h, int B, int N, double* ctrl, const int32_t* guide_off, const double* guide_pv,
+                        const uint8_t* guide_unk, const int32_t* obs_off, const double* obs, int n_obs_shared, double* weights,
+                        double gate_dt, double not_check_ratio, int max_rounds, vigo_rebound_state_t* state) {
+    int rc = check_solve_args(h, B, N, ctrl);
+    if (rc) return rc;
+    rc = check_list_args(h, guide_off, guide_pv, obs_off, obs, n_obs_shared);
+    if (rc) return rc;
+    if (B > 0 && (!weights || !state)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_rebound_rounds: weights and state are required");
+    if (max_rounds < 0 || max_rounds > 64 || !(not_check_ratio >= 0.0 && not_check_ratio < 1.0))
+        return fail(h, VIGO_ERR_INVALID_ARG, "vigo_rebound_rounds: max_rounds outside [0, 64] or not_check_ratio outside [0, 1)");
+    if (!h->has_grid) return fail(h, VIGO_ERR_NO_GRID, "vigo_rebound_rounds before vigo_set_grid");
+    if (vigo::optimize_lds_requirement(N, h->params.mem_size, h->precision) > (size_t)160 * 1024)
+        return fail(h, VIGO_ERR_UNSUPPORTED_N, "the L-BFGS history of N control points x mem_size does not fit the 160 KiB LDS of a CU");
+    if (B == 0) return VIGO_OK;
+    int T = 0;
+    const double* times = nullptr;
+    rc = upload_sample_times(h, (N - 3) * h->params.ts_ctrl, gate_dt, &T, &times);
+    if (rc) return rc;
+    // compacted active set: B indices + the count (its own allocation: the scratch buffer serves other entry points)
+    if ((size_t)B + 16 > h->rebound_cap) {
+        if (h->rebound_idx) (void)hipFree(h->rebound_idx);
+        h->rebound_idx = nullptr;
+        h->rebound_cap = 0;
+        VIGO_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->rebound_idx), ((size_t)B + 16) * sizeof(int32_t) + 64));
+        h->rebound_cap = (size_t)B + 16;
+    }
+    int32_t* idx = h->rebound_idx + 16;
+    int32_t* count = h->rebound_idx;          // flags[0]; flags[1], flags[2]: "a trajectory waits for the host"
+    VIGO_HIP(h, hipMemsetAsync(count, 0, 16 * sizeof(int32_t), h->stream));
+    SolveArgs a{};
+    a.B = B; a.N = N;
+    a.ctrl = ctrl;
+    a.guide_off = guide_off; a.guide_pv = guide_pv; a.guide_unk = guide_unk;
+    a.obs_off = obs_off; a.obs = obs; a.n_obs_shared = n_obs_shared;
+    a.weights = weights;
+    a.active_idx = idx; a.active_count = count;
+    a.out_status = &state[0].lbfgs_status;
+    a.status_stride = (int)(sizeof(vigo_rebound_state_t) / sizeof(int32_t));
+    vigo::ReboundArgs r{};
+    r.B = B; r.N = N; r.ctrl = ctrl;
+    r.guide_off = guide_off; r.guide_pv = guide_pv;
+    r.obs_off = obs_off; r.obs = obs; r.n_obs_shared = n_obs_shared;
+    r.weights = weights; r.state = state;
+    r.ts_ctrl = h->params.ts_ctrl; r.T = T; r.times = times;
+    r.dthresh = h->params.dthresh; r.not_check_ratio = not_check_ratio;
+    r.flags = count;
+    // the optimize() a trajectory still owes (BT.cpp:612 / after a host-side re-guide) ...
+    VIGO_HIP(h, (hipError_t)vigo::launch_rebound_compact(h->stream, B, state, 0, idx, count));
+    VIGO_HIP(h, (hipError_t)vigo::launch_optimize(h->stream, a, h->dc, h->dc_dev, h->precision, h->launch));
+    // ... then the rounds: gates + decision, compaction of the still-active set, optimize
+    for (int round = 0; round < max_rounds; ++round) {
+        VIGO_HIP(h, (hipError_t)vigo::launch_rebound_decide(h->stream, h->grid, r));
+        VIGO_HIP(h, (hipError_t)vigo::launch_rebound_compact(h->stream, B, state, 1, idx, count));
+        VIGO_HIP(h, (hipError_t)vigo::launch_optimize(h->stream, a, h->dc, h->dc_dev, h->precision, h->launch));
+    }
     return VIGO_OK;
 }
 

@@ -43,6 +43,11 @@ struct SolveArgs {
     const double* obs;
     int n_obs_shared;
     const double* weights;
+    // (vigo_rebound_rounds) the launch works on trajectory active_idx[slot] for slot < *active_count instead of
+    // b = slot < B; lbfgs_status_stride != 0: out_status is the lbfgs_status field of a vigo_rebound_state_t array
+    const int32_t* active_idx;
+    const int32_t* active_count;
+    int status_stride;     // in int32 units between consecutive trajectories' out_status (0 = 1)
     // optimize outputs
     double* out_x;
     int32_t* out_status;
@@ -119,6 +124,26 @@ int launch_box_points(hipStream_t s, const GridView& g, int64_t M, const double*
 // polyTrajSolver::getTrajectory for S segments: sample k of segment s at out[(s * stride + k) * 3] (fp64 and/or float)
 int launch_poly_sample(hipStream_t s, int S, int deg, const double* coeffs, const int32_t* n_samp, const double* delT,
                        int stride, double* out_pos, float* out_f32);
+// the gate + decision pass of vigo_rebound_rounds (one wave per trajectory) and the compaction of the active set
+struct ReboundArgs {
+    int B, N;
+    const double* ctrl;
+    const int32_t* guide_off;
+    const double* guide_pv;
+    const int32_t* obs_off;
+    const double* obs;
+    int n_obs_shared;
+    double* weights;
+    vigo_rebound_state_t* state;
+    double ts_ctrl;
+    int T;
+    const double* times;
+    double dthresh, not_check_ratio;
+    int32_t* flags;          // see k_rebound_compact
+};
+int launch_rebound_decide(hipStream_t s, const GridView& g, const ReboundArgs& a);
+// mode 0: status == ACTIVE && solve_first (clears solve_first); mode 1: status == ACTIVE.  Ascending order.
+int launch_rebound_compact(hipStream_t s, int B, vigo_rebound_state_t* state, int mode, int32_t* idx, int32_t* flags);
 // counts CSR violations of guide_off[B*N+1] / obs_off[B+1] into *bad (device int, zeroed by the launcher)
 int launch_check_lists(hipStream_t s, int B, int N, const int32_t* guide_off, int64_t G, const int32_t* obs_off, int64_t O,
                        int* bad);
@@ -177,6 +202,9 @@ struct vigo_context {
     double times_dt = -1.0, times_tmax = -1.0;
     int times_T = -1;
     hipStream_t times_stream = nullptr;
+    // vigo_rebound_rounds: count (16 ints, first used) + compacted indices
+    int32_t* rebound_idx = nullptr;
+    size_t rebound_cap = 0;    // trajectories
     // scratch (sample-time tables, corridor checkpoints, staging of *_host calls)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;

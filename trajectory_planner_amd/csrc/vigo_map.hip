@@ -216,6 +216,22 @@ __global__ void __launch_bounds__(64) k_traj_dynamic_collision(int B, int N, con
     if (threadIdx.x == 0) out_flag[b] = (uint8_t)(hit != 0);
 }
 
+// isInflatedOccupiedLine(q, p) of the dense map contract (include/vigo.h), given the point flags of both ends:
+// end points, then int(dist / res) - 1 interior steps of length res from q
+__device__ __forceinline__ unsigned line_occupied(const GridView& g, const double* q, const double* p, unsigned occ_q, unsigned occ_p) {
+    unsigned line = occ_q | occ_p;
+    if (!line) {
+        const double d0 = p[0] - q[0], d1 = p[1] - q[1], d2 = p[2] - q[2];
+        const double dist = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
+        const double i0 = d0 / dist * g.res, i1 = d1 / dist * g.res, i2 = d2 / dist * g.res;
+        const int steps = (int)(dist / g.res);
+        for (int s = 1; s < steps; ++s) {
+            if (grid_plane_pos(g, 0, q[0] + s * i0, q[1] + s * i1, q[2] + s * i2)) { line = 1; break; }
+        }
+    }
+    return line;
+}
+
 // one thread per control point: point flag and the line (i-1, i) flag
 __global__ void k_ctrl_occupancy(GridView g, int B, int N, const double* __restrict__ ctrl,
                                  uint8_t* __restrict__ out_pt, uint8_t* __restrict__ out_line) {
@@ -228,18 +244,190 @@ __global__ void k_ctrl_occupancy(GridView g, int B, int N, const double* __restr
     unsigned line = 0;
     if (i > 0) {
         const double* q = p - 3;  // previous control point
-        line = grid_plane_pos(g, 0, q[0], q[1], q[2]) | occ;
-        if (!line) {
-            const double d0 = p[0] - q[0], d1 = p[1] - q[1], d2 = p[2] - q[2];
-            const double dist = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
-            const double i0 = d0 / dist * g.res, i1 = d1 / dist * g.res, i2 = d2 / dist * g.res;
-            const int steps = (int)(dist / g.res);
-            for (int s = 1; s < steps; ++s) {
-                if (grid_plane_pos(g, 0, q[0] + s * i0, q[1] + s * i1, q[2] + s * i2)) { line = 1; break; }
-            }
-        }
+        line = line_occupied(g, q, p, grid_plane_pos(g, 0, q[0], q[1], q[2]), occ);
     }
     out_line[idx] = (uint8_t)line;
+}
+
+// ---- vigo_rebound_rounds: gates + the loop body of bsplineTraj::optimizeTrajectory (BT.cpp:619-679) ----------
+// One 64-lane wave per ACTIVE trajectory.  The gates are the kernels above (lanes stride over the samples); the
+// map queries of findCollisionSeg run one control point per lane; the segment bookkeeping, the comparison with the
+// previous segments and the guide test are a serial scan by lane 0 over a few dozen bytes in LDS.
+__global__ void __launch_bounds__(64) k_rebound_decide(GridView g, ReboundArgs A) {
+    __shared__ uint8_t s_pt[VIGO_MAX_CTRL_POINTS], s_ln[VIGO_MAX_CTRL_POINTS];
+    __shared__ int s_need_host;
+    const int b = blockIdx.x;
+    if (b >= A.B) return;
+    // a trajectory of an EARLIER round waits for the host (A*): the queued rounds that follow are no-ops for the whole
+    // batch, like the lock-step of the host-driven loop — the waiting trajectories are on the batch's critical path
+    if (A.flags[1] != 0) return;
+    vigo_rebound_state_t& st = A.state[b];
+    if (st.status != VIGO_RB_ACTIVE) return;
+    const int N = A.N, lane = threadIdx.x;
+    const double* c = A.ctrl + (size_t)b * N * 3;
+
+    // hasCollisionTrajectory, BT.h:307-325 (same walk as k_traj_collision)
+    int col = 0;
+    for (int k = lane; k < A.T && !col; k += 64) {
+        double p[3];
+        traj_eval(c, N, A.ts_ctrl, 0, A.times[k], p);
+        if (grid_plane_pos(g, 0, p[0], p[1], p[2])) col = 1;
+    }
+    col = __any(col) ? 1 : 0;
+    // hasDynamicCollisionTrajectory, BT.h:344-368 — only for a trajectory that has obstacles (BT.cpp:621-626)
+    const int o0 = (A.obs && A.obs_off) ? A.obs_off[b] : 0;
+    const int o1 = !A.obs ? 0 : (A.obs_off ? A.obs_off[b + 1] : A.n_obs_shared);
+    int dyn = 0;
+    if (o1 > o0) {
+        for (int k = lane; k < A.T && !dyn; k += 64) {
+            double p[3];
+            traj_eval(c, N, A.ts_ctrl, 0, A.times[k], p);
+            for (int j = o0; j < o1; ++j) {
+                const double* o = A.obs + 9 * (size_t)j;
+                const double size = fmin(o[6] / 2, o[7] / 2);
+                const double dx = p[0] - o[0], dy = p[1] - o[1];
+                if (sqrt((dx * dx + dy * dy) + 0.0) - size < 0) { dyn = 1; break; }
+            }
+        }
+        dyn = __any(dyn) ? 1 : 0;
+    }
+    if (lane == 0) {
+        st.gate_static = col;
+        st.gate_dynamic = dyn;
+        st.rounds += 1;
+    }
+    if (!col && !dyn) {                                   // BT.cpp:628-631
+        if (lane == 0) st.status = VIGO_RB_DONE;
+        return;
+    }
+    if (st.fail_count >= 4) {                             // BT.cpp:640-654: forced A* re-guide, the host's
+        if (lane == 0) { st.status = VIGO_RB_NEEDS_HOST; A.flags[2] = 1; }
+        return;
+    }
+    if (col) {
+        // the map queries of findCollisionSeg (BT.cpp:412, :435), one control point per lane
+        for (int i = lane; i < N; i += 64) {
+            const double* p = c + 3 * i;
+            s_pt[i] = (uint8_t)grid_plane_pos(g, 0, p[0], p[1], p[2]);
+        }
+        __syncthreads();
+        for (int i = lane; i < N; i += 64)
+            s_ln[i] = i > 0 ? (uint8_t)line_occupied(g, c + 3 * (i - 1), c + 3 * i, s_pt[i - 1], s_pt[i]) : 0;
+        __syncthreads();
+        if (lane == 0) {
+            // findCollisionSeg, BT.cpp:403-445 (incl. the corner case that can duplicate a segment)
+            int seg[2 * VIGO_MAX_COLLISION_SEGS];
+            int n_new = 0;
+            auto push = [&](int a, int e) {
+                if (n_new < VIGO_MAX_COLLISION_SEGS) { seg[2 * n_new] = a; seg[2 * n_new + 1] = e; }
+                ++n_new;
+            };
+            bool prev_has = false;
+            const int end_idx = (int)((N - 3 - 1) - A.not_check_ratio * (N - 2 * 3));
+            int pair_start = 3, pair_end = 3;
+            for (int i = 3; i <= end_idx; ++i) {
+                const bool has = s_pt[i] != 0;
+                if (has != prev_has) {
+                    if (has) pair_start = i - 1;
+                    else { pair_end = i; push(pair_start, pair_end); }
+                }
+                if (has && i == end_idx - 1) { pair_end = N - 1; push(pair_start, pair_end); }
+                if (i != 3 && !prev_has && !has && s_ln[i]) push(i - 1, i);
+                prev_has = has;
+            }
+            bool need_host = n_new > VIGO_MAX_COLLISION_SEGS;
+            // isReguideRequired, BT.cpp:573-608: a control point inside a new segment that no previous segment covers,
+            // or a covered one that fails isControlPointRequireNewGuide (BT.h:417-429), asks for A*
+            if (!need_host) {
+                const int n_prev = st.n_seg;
+                auto in_prev = [&](int i) {
+                    for (int k = 0; k < n_prev; ++k)
+                        if (i >= st.seg[2 * k] && i <= st.seg[2 * k + 1]) return true;
+                    return false;
+                };
+                auto require_new_guide = [&](int i) {
+                    if (!A.guide_off || !A.guide_pv) return true;
+                    const double* ci = c + 3 * i;
+                    for (int j = A.guide_off[(size_t)b * N + i]; j < A.guide_off[(size_t)b * N + i + 1]; ++j) {
+                        const double* pv = A.guide_pv + 6 * (size_t)j;
+                        const double dist = ((ci[0] - pv[0]) * pv[3] + (ci[1] - pv[1]) * pv[4]) + (ci[2] - pv[2]) * pv[5];
+                        if (A.dthresh - dist > 0) return false;
+                    }
+                    return true;
+                };
+                auto asks = [&](int i) { return !in_prev(i) || require_new_guide(i); };
+                for (int k = 0; k < n_new && !need_host; ++k) {
+                    const int a = seg[2 * k], e = seg[2 * k + 1];
+                    for (int i = a + 1; i <= e - 1 && !need_host; ++i) need_host = asks(i);
+                    if (e - a - 1 == 0)
+                        for (int i = a; i <= e && !need_host; ++i) need_host = asks(i);
+                }
+            }
+            s_need_host = need_host ? 1 : 0;
+            if (need_host) {
+                st.status = VIGO_RB_NEEDS_HOST;           // untouched state: the host repeats the step with its own A*
+                A.flags[2] = 1;
+            } else {
+                st.n_seg = n_new;                         // collisionSeg_ = the new segments (BT.cpp:575)
+                for (int k = 0; k < 2 * n_new; ++k) st.seg[k] = seg[k];
+                A.weights[4 * (size_t)b + 0] *= 2.0;      // BT.cpp:672
+                st.fail_count += 1;
+            }
+        }
+        __syncthreads();
+        if (s_need_host) return;
+    }
+    if (dyn && lane == 0) A.weights[4 * (size_t)b + 3] *= 2.0;   // BT.cpp:677-679
+}
+
+// ascending indices of the trajectories a launch works on: one block, a scan over per-thread counts
+// flags: [0] = count (out), [1] = "a trajectory waits for the host since an earlier round" (read by this round's
+// kernels), [2] = the same as raised by this round's decide pass; mode 1 publishes [2] into [1] for the next round
+__global__ void __launch_bounds__(1024) k_rebound_compact(int B, vigo_rebound_state_t* __restrict__ state, int mode,
+                                                          int32_t* __restrict__ idx, int32_t* __restrict__ flags) {
+    __shared__ int s_cnt[1024];
+    const int tid = threadIdx.x;
+    int32_t* count = flags;
+    if (mode == 1 && flags[1] != 0) {            // (uniform: every thread reads the same word)
+        if (tid == 0) *count = 0;
+        return;
+    }
+    if (mode == 1 && flags[2] != 0) {
+        // this round's decisions hand a trajectory to the host: the optimize() the still-active trajectories owe is
+        // deferred to the caller's next call (solve_first), where it shares ONE launch with the re-guided ones —
+        // two launches in a row would put two solve latencies on the batch's critical path
+        const int per_ = (B + 1023) / 1024;
+        for (int b = min(B, tid * per_); b < min(B, tid * per_ + per_); ++b)
+            if (state[b].status == VIGO_RB_ACTIVE) state[b].solve_first = 1;
+        if (tid == 0) { *count = 0; flags[1] = 1; }
+        return;
+    }
+    const int per = (B + 1023) / 1024;
+    const int lo = min(B, tid * per), hi = min(B, lo + per);
+    auto wanted = [&](int b) {
+        return state[b].status == VIGO_RB_ACTIVE && (mode == 1 || state[b].solve_first != 0);
+    };
+    int n = 0;
+    for (int b = lo; b < hi; ++b) n += wanted(b) ? 1 : 0;
+    s_cnt[tid] = n;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {            // inclusive scan
+        const int v = tid >= off ? s_cnt[tid - off] : 0;
+        __syncthreads();
+        s_cnt[tid] += v;
+        __syncthreads();
+    }
+    int at = s_cnt[tid] - n;
+    for (int b = lo; b < hi; ++b) {
+        if (wanted(b)) {
+            idx[at++] = b;
+            if (mode == 0) state[b].solve_first = 0;
+        }
+    }
+    if (tid == 1023) {
+        *count = s_cnt[1023];
+        if (mode == 1) flags[1] = flags[2];
+    }
 }
 
 }  // namespace
@@ -323,6 +511,17 @@ int launch_traj_dynamic_collision(hipStream_t s, int B, int N, const double* ctr
 int launch_fill_sample_times(hipStream_t s, double dt, int T, double* times) {
     if (T <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_fill_sample_times, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, dt, T, times);
+    return (int)hipGetLastError();
+}
+
+int launch_rebound_decide(hipStream_t s, const GridView& g, const ReboundArgs& a) {
+    if (a.B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rebound_decide, dim3(a.B), dim3(64), 0, s, g, a);
+    return (int)hipGetLastError();
+}
+
+int launch_rebound_compact(hipStream_t s, int B, vigo_rebound_state_t* state, int mode, int32_t* idx, int32_t* flags) {
+    hipLaunchKernelGGL(k_rebound_compact, dim3(1), dim3(1024), 0, s, B, state, mode, idx, flags);
     return (int)hipGetLastError();
 }
 

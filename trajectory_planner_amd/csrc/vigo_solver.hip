@@ -813,8 +813,13 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 
     const int lane = threadIdx.x;
     const int grp = lane / GROUP;
-    const int b = blockIdx.x * TPB + grp;
-    if (b >= A.B) return;
+    int b = blockIdx.x * TPB + grp;
+    if (A.active_idx) {                       // vigo_rebound_rounds: the compacted active set
+        if (b >= *A.active_count) return;
+        b = A.active_idx[b];
+    } else if (b >= A.B) {
+        return;
+    }
 
     LaneProblem<T, PPL> Q;
     load_problem<T, GROUP, PPL>(A, K, b, lane % GROUP, Q);
@@ -1250,7 +1255,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
     }
 #endif
     if (lane % GROUP == 0) {
-        if (A.out_status) A.out_status[b] = ret;
+        if (A.out_status) A.out_status[(size_t)b * (A.status_stride ? A.status_stride : 1)] = ret;
         if (A.out_fx) A.out_fx[b] = fx;
         if (A.out_iters) A.out_iters[b] = k;
         if (A.out_evals) A.out_evals[b] = evals;

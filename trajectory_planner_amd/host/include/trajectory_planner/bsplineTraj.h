@@ -25,6 +25,7 @@
 
 const int bsplineDegree = 3;
 struct vigo_context;
+struct vigo_params_s;
 
 namespace trajPlanner {
 struct optData {
@@ -69,6 +70,9 @@ private:
         double w0 = 0, wo0 = 0;
         int failCount = 0;
         bool done = false, ok = false, needOptimize = true;
+        // filled by the device-resident rounds (vigo_rebound_rounds) for the host's part of the loop
+        int devStatus = 0;
+        bool gateStatic = false, gateDynamic = false;
     };
 
 public:
@@ -90,8 +94,13 @@ public:
 
     bool makePlan();
     bool makePlan(nav_msgs::Path& trajectory, bool yaw = true);
-    /* all planners must share one map object; returns per-planner success like makePlan() */
+    /* Planners are grouped by control-point count, map object and every hot-path parameter (the yaml values, maxVel):
+     * each group is one batch on the device.  Returns per-planner success like makePlan(). */
     static std::vector<bool> makePlanBatch(const std::vector<bsplineTraj*>& planners);
+    /* The rebound loop of BT.cpp:611-685 runs on the device between two A* calls (vigo_rebound_rounds, default) or
+     * round by round from the host (the round-1 path, kept for comparison: identical control points). */
+    static void setDeviceResidentRebound(bool on);
+    static bool deviceResidentRebound();
     /* updatePath() for many planners at once: the least-squares fits run as one device launch */
     static std::vector<bool> updatePathBatch(const std::vector<bsplineTraj*>& planners, const std::vector<nav_msgs::Path>& paths,
                                              const std::vector<std::vector<Eigen::Vector3d>>& startEndConditions);
@@ -130,6 +139,7 @@ public:
     bool isCurrTrajValid();
     bool isCurrTrajValid(Eigen::Vector3d& firstCollisionPos);
     int getLastSolverStatus() const { return lastStatus_; }
+    bool hasDynamicObstacles() const { return !optData_.dynamicObstaclesPos.empty(); }
 
     std::vector<Eigen::Vector3d> evalTraj();
     std::vector<Eigen::Vector3d> evalTraj(double dt);
@@ -155,7 +165,13 @@ private:
     bool prepareFitPoints(const nav_msgs::Path& adjustedPath, std::vector<Eigen::Vector3d>& adjustedCurveFitPoints);
     void installControlPoints(const Eigen::MatrixXd& controlPoints, const std::vector<Eigen::Vector3d>& adjustedCurveFitPoints);
     bool termCost(int term, const Eigen::MatrixXd& controlPoints, double& cost, Eigen::MatrixXd& gradient);
+    void reboundFinish(Rebound& r, bool ok);
+    bool sameBatchKey(const bsplineTraj& o) const;                  // may share a device batch with o
+    void fillParams(vigo_params_s* P) const;
     static void solveBatch(const std::vector<bsplineTraj*>& ps);   // one vigo_optimize for all
+    /* up to maxRounds rounds of the loop on the device for one group; fills rb[i]->devStatus / gate flags and the
+     * planners' control points, weights, failCount, collisionSeg_.  false: device failure (nothing usable) */
+    static bool deviceRounds(const std::vector<bsplineTraj*>& grp, const std::vector<Rebound*>& rb, int maxRounds);
     static void gateBatch(const std::vector<bsplineTraj*>& ps, std::vector<uint8_t>& col, std::vector<uint8_t>& dyn);
 };
 }  // namespace trajPlanner

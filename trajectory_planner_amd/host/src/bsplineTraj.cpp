@@ -112,16 +112,9 @@ void bsplineTraj::setMap(const std::shared_ptr<mapManager::occMap>& map) {
 void bsplineTraj::updateMaxVel(double maxVel) { this->maxVel_ = maxVel; }
 void bsplineTraj::updateMaxAcc(double maxAcc) { this->maxAcc_ = maxAcc; }
 
-// handle creation, parameter push and (re)snapshot of the map when its version moved
-bool bsplineTraj::syncDevice() {
-    if (!dev_) {
-        if (vigo_create(&dev_, 0) != VIGO_OK) {
-            cout << "[BsplineTraj]: no HIP device for the ViGO back-end (there is no CPU fallback)." << endl;
-            dev_ = nullptr;
-            return false;
-        }
-    }
-    vigo_params_t P;
+// every hot-path parameter the device sees for this planner
+void bsplineTraj::fillParams(vigo_params_s* Pp) const {
+    vigo_params_t& P = *Pp;
     vigo_default_params(&P);
     P.dthresh = dthresh_;
     P.dist_thresh_dynamic = distThreshDynamic_;
@@ -139,6 +132,36 @@ bool bsplineTraj::syncDevice() {
     P.mem_size = 16;          // BT.cpp:697
     P.max_iterations = 200;   // BT.cpp:698
     P.g_epsilon = 0.01;       // BT.cpp:699
+}
+
+// Two planners may share a device batch when the lead's handle state fits both: the same map object, the same
+// control-point count, gate step (maxVel_) and every parameter of fillParams() except the four weights, which
+// travel per trajectory.
+bool bsplineTraj::sameBatchKey(const bsplineTraj& o) const {
+    if (map_ != o.map_ || maxVel_ != o.maxVel_ || notCheckRatio_ != o.notCheckRatio_ ||
+        optData_.controlPoints.cols() != o.optData_.controlPoints.cols())
+        return false;
+    vigo_params_t a, b;
+    this->fillParams(&a);
+    o.fillParams(&b);
+    a.w_distance = b.w_distance; a.w_smoothness = b.w_smoothness; a.w_feasibility = b.w_feasibility; a.w_dynamic = b.w_dynamic;
+    return std::memcmp(&a, &b, sizeof(a)) == 0;
+}
+
+// handle creation, parameter push and (re)snapshot of the map when its version moved
+bool bsplineTraj::syncDevice() {
+    if (!dev_) {
+        if (vigo_create(&dev_, 0) != VIGO_OK) {
+            cout << "[BsplineTraj]: no HIP device for the ViGO back-end (there is no CPU fallback)." << endl;
+            dev_ = nullptr;
+            return false;
+        }
+    }
+    // launches and staging copies of this call go to the calling thread's stream (two host threads planning two
+    // batches then overlap on the device)
+    if (vigo_set_stream(dev_, vigo_host::threadStream()) != VIGO_OK) return false;
+    vigo_params_t P;
+    this->fillParams(&P);
     if (vigo_set_params(dev_, &P) != VIGO_OK) return false;
     if (map_ && mapVersion_ != map_->version) {
         const double o[3] = {map_->origin()(0), map_->origin()(1), map_->origin()(2)};
@@ -284,7 +307,7 @@ std::vector<bool> bsplineTraj::updatePathBatch(const std::vector<bsplineTraj*>& 
             cout << "[BsplineTraj]: vigo_bspline_fit failed: " << vigo_last_error(lead->dev_) << endl;
             continue;
         }
-        if (hipDeviceSynchronize() != hipSuccess || !dCtrl.download(ctrl.data(), ctrl.size() * 8)) continue;
+        if (!vigo_host::threadSync() || !dCtrl.download(ctrl.data(), ctrl.size() * 8)) continue;
         for (int b = 0; b < B; ++b) {
             Eigen::MatrixXd controlPoints;
             controlPoints.resize(3, K + 2);
@@ -576,7 +599,7 @@ void bsplineTraj::solveBatch(const std::vector<bsplineTraj*>& ps) {
         const int N = ps[a]->optData_.controlPoints.cols();
         std::vector<bsplineTraj*> grp;
         for (size_t b = a; b < ps.size(); ++b)
-            if (!doneMask[b] && ps[b]->optData_.controlPoints.cols() == N) { grp.push_back(ps[b]); doneMask[b] = true; }
+            if (!doneMask[b] && ps[a]->sameBatchKey(*ps[b])) { grp.push_back(ps[b]); doneMask[b] = true; }
         bsplineTraj* lead = grp[0];
         for (auto* p : grp) p->lastStatus_ = VIGO_ERR_HIP;
         if (N < 7 || N > VIGO_MAX_CTRL_POINTS || !lead->syncDevice()) continue;
@@ -629,7 +652,7 @@ void bsplineTraj::solveBatch(const std::vector<bsplineTraj*>& ps) {
             continue;
         }
         std::vector<int32_t> status(hb.B);
-        if (hipDeviceSynchronize() != hipSuccess || !dCtrl.download(hb.ctrl.data(), hb.ctrl.size() * 8) ||
+        if (!vigo_host::threadSync() || !dCtrl.download(hb.ctrl.data(), hb.ctrl.size() * 8) ||
             !dStatus.download(status.data(), status.size() * 4))
             continue;
         for (int b = 0; b < hb.B; ++b) {
@@ -649,7 +672,7 @@ void bsplineTraj::gateBatch(const std::vector<bsplineTraj*>& ps, std::vector<uin
         const int N = ps[a]->optData_.controlPoints.cols();
         std::vector<size_t> idx;
         for (size_t b = a; b < ps.size(); ++b)
-            if (!doneMask[b] && ps[b]->optData_.controlPoints.cols() == N && ps[b]->maxVel_ == ps[a]->maxVel_) {
+            if (!doneMask[b] && ps[a]->sameBatchKey(*ps[b])) {
                 idx.push_back(b);
                 doneMask[b] = true;
             }
@@ -680,7 +703,7 @@ void bsplineTraj::gateBatch(const std::vector<bsplineTraj*>& ps, std::vector<uin
                                             (const double*)dObs.p, 0, (uint8_t*)dDyn.p) != VIGO_OK)
                 continue;
         }
-        if (hipDeviceSynchronize() != hipSuccess || !dFlag.download(f.data(), B)) continue;
+        if (!vigo_host::threadSync() || !dFlag.download(f.data(), B)) continue;
         if (!obs.empty() && !dDyn.download(d.data(), B)) continue;
         for (int b = 0; b < B; ++b) {
             col[idx[b]] = f[b];
@@ -688,6 +711,119 @@ void bsplineTraj::gateBatch(const std::vector<bsplineTraj*>& ps, std::vector<uin
             dyn[idx[b]] = ps[idx[b]]->optData_.dynamicObstaclesPos.empty() ? 0 : d[b];
         }
     }
+}
+
+namespace {
+std::atomic<bool> g_deviceResidentRebound{true};
+}
+void bsplineTraj::setDeviceResidentRebound(bool on) { g_deviceResidentRebound.store(on); }
+bool bsplineTraj::deviceResidentRebound() { return g_deviceResidentRebound.load(); }
+
+// BT.cpp:611-685 between two A* calls, on the device, for one group of planners (one batch): upload the planners'
+// state, queue the rounds (vigo_rebound_rounds), bring back what the host part of the loop needs.
+bool bsplineTraj::deviceRounds(const std::vector<bsplineTraj*>& grp, const std::vector<Rebound*>& rb, int maxRounds) {
+    if (grp.empty()) return true;
+    bsplineTraj* lead = grp[0];
+    const int N = lead->optData_.controlPoints.cols();
+    std::vector<int> prevStatus(grp.size());
+    for (size_t k = 0; k < grp.size(); ++k) { prevStatus[k] = grp[k]->lastStatus_; grp[k]->lastStatus_ = VIGO_ERR_HIP; }
+    if (N < 7 || N > VIGO_MAX_CTRL_POINTS || !lead->syncDevice()) return false;
+    HostBatch hb;
+    hb.B = (int)grp.size();
+    hb.N = N;
+    hb.goff.push_back(0);
+    hb.ooff.push_back(0);
+    std::vector<vigo_rebound_state_t> state(grp.size());
+    for (size_t k = 0; k < grp.size(); ++k) {
+        bsplineTraj* p = grp[k];
+        const double* c = p->optData_.controlPoints.data();
+        hb.ctrl.insert(hb.ctrl.end(), c, c + 3 * N);
+        for (int i = 0; i < N; ++i) {
+            const size_t cnt = i < (int)p->optData_.guidePoints.size() ? p->optData_.guidePoints[i].size() : 0;
+            for (size_t j = 0; j < cnt; ++j) {
+                const Eigen::Vector3d& g = p->optData_.guidePoints[i][j];
+                const Eigen::Vector3d& v = p->optData_.guideDirections[i][j];
+                for (int q = 0; q < 3; ++q) hb.gpv.push_back(g(q));
+                for (int q = 0; q < 3; ++q) hb.gpv.push_back(v(q));
+            }
+            hb.goff.push_back((int32_t)(hb.gpv.size() / 6));
+        }
+        for (size_t j = 0; j < p->optData_.dynamicObstaclesPos.size(); ++j) {
+            for (int q = 0; q < 3; ++q) hb.obs.push_back(p->optData_.dynamicObstaclesPos[j](q));
+            for (int q = 0; q < 3; ++q) hb.obs.push_back(p->optData_.dynamicObstaclesVel[j](q));
+            for (int q = 0; q < 3; ++q) hb.obs.push_back(p->optData_.dynamicObstaclesSize[j](q));
+        }
+        hb.ooff.push_back((int32_t)(hb.obs.size() / 9));
+        hb.weights.push_back(p->weightDistance_);
+        hb.weights.push_back(p->weightSmoothness_);
+        hb.weights.push_back(p->weightFeasibility_);
+        hb.weights.push_back(p->weightDynamicObstacle_);
+        vigo_rebound_state_t& st = state[k];
+        std::memset(&st, 0, sizeof(st));
+        st.status = VIGO_RB_ACTIVE;
+        st.lbfgs_status = prevStatus[k];      // kept when this call makes no optimize() for the planner
+        st.solve_first = rb[k]->needOptimize ? 1 : 0;
+        st.fail_count = rb[k]->failCount;
+        st.n_seg = (int32_t)p->collisionSeg_.size();
+        if (st.n_seg > VIGO_MAX_COLLISION_SEGS) {
+            // more previous segments than the device state holds: this planner's rounds stay with the host (one gate,
+            // then reboundStep) — a trajectory of VIGO_MAX_CTRL_POINTS control points can get there, a 7 m path cannot
+            st.status = VIGO_RB_NEEDS_HOST;
+            st.n_seg = 0;
+        } else {
+            for (int q = 0; q < st.n_seg; ++q) { st.seg[2 * q] = p->collisionSeg_[q].first; st.seg[2 * q + 1] = p->collisionSeg_[q].second; }
+        }
+    }
+    const size_t G = hb.gpv.size() / 6;
+    static thread_local StagingBuf dCtrl, dGoff, dGpv, dGunk, dOoff, dObs, dW, dState;
+    bool ok = dCtrl.upload(hb.ctrl.data(), hb.ctrl.size() * 8) && dGoff.upload(hb.goff.data(), hb.goff.size() * 4) &&
+              dGpv.upload(hb.gpv.data(), hb.gpv.size() * 8) && dGunk.alloc(G) && dOoff.upload(hb.ooff.data(), hb.ooff.size() * 4) &&
+              dObs.upload(hb.obs.data(), hb.obs.size() * 8) && dW.upload(hb.weights.data(), hb.weights.size() * 8) &&
+              dState.upload(state.data(), state.size() * sizeof(vigo_rebound_state_t));
+    if (!ok) return false;
+    vigo_handle_t h = lead->dev_;
+    if (G && vigo_guides_unknown(h, (int64_t)G, (const double*)dGpv.p, (uint8_t*)dGunk.p) != VIGO_OK) return false;
+    const double dt = lead->map_->getRes() / lead->maxVel_ / 2.0;  // BT.h:312
+    if (vigo_rebound_rounds(h, hb.B, N, (double*)dCtrl.p, (const int32_t*)dGoff.p, G ? (const double*)dGpv.p : nullptr,
+                            G ? (const uint8_t*)dGunk.p : nullptr, (const int32_t*)dOoff.p, hb.obs.empty() ? nullptr : (const double*)dObs.p, 0,
+                            (double*)dW.p, dt, lead->notCheckRatio_, maxRounds, (vigo_rebound_state_t*)dState.p) != VIGO_OK) {
+        cout << "[BsplineTraj]: vigo_rebound_rounds failed: " << vigo_last_error(h) << endl;
+        return false;
+    }
+    if (!vigo_host::threadSync() || !dCtrl.download(hb.ctrl.data(), hb.ctrl.size() * 8) ||
+        !dW.download(hb.weights.data(), hb.weights.size() * 8) || !dState.download(state.data(), state.size() * sizeof(vigo_rebound_state_t)))
+        return false;
+    std::vector<bsplineTraj*> overflow;
+    std::vector<size_t> overflowAt;
+    for (size_t k = 0; k < grp.size(); ++k) {
+        bsplineTraj* p = grp[k];
+        const vigo_rebound_state_t& st = state[k];
+        if (st.rounds == 0 && st.status == VIGO_RB_NEEDS_HOST) { overflow.push_back(p); overflowAt.push_back(k); continue; }
+        // optData_.controlPoints = the last evaluated point, as costFunction leaves it (BT.cpp:803)
+        std::memcpy(p->optData_.controlPoints.data(), hb.ctrl.data() + k * 3 * N, sizeof(double) * 3 * N);
+        p->weightDistance_ = hb.weights[4 * k + 0];
+        p->weightDynamicObstacle_ = hb.weights[4 * k + 3];
+        p->lastStatus_ = st.lbfgs_status;
+        p->collisionSeg_.clear();
+        for (int q = 0; q < st.n_seg; ++q) p->collisionSeg_.push_back({st.seg[2 * q], st.seg[2 * q + 1]});
+        rb[k]->failCount = st.fail_count;
+        rb[k]->needOptimize = st.solve_first != 0;     // an optimize() the device deferred to the next call
+        rb[k]->devStatus = st.status;
+        rb[k]->gateStatic = st.gate_static != 0;
+        rb[k]->gateDynamic = st.gate_dynamic != 0;
+    }
+    // planners the device state cannot represent: one host-driven round (solve if owed, gate; the caller steps)
+    for (size_t q = 0; q < overflow.size(); ++q) {
+        std::vector<bsplineTraj*> one{overflow[q]};
+        Rebound& r = *rb[overflowAt[q]];
+        if (r.needOptimize) solveBatch(one);
+        std::vector<uint8_t> col, dyn;
+        gateBatch(one, col, dyn);
+        r.gateStatic = col[0] != 0;
+        r.gateDynamic = dyn[0] != 0;
+        r.devStatus = (!r.gateStatic && !r.gateDynamic) ? VIGO_RB_DONE : VIGO_RB_NEEDS_HOST;
+    }
+    return true;
 }
 
 // BT.cpp:687-718
@@ -728,7 +864,7 @@ double bsplineTraj::costFunction(const double* x, double* grad, const int n) {
                        (int)(obs.size() / 9), nullptr, (double*)dCost.p, (double*)dGrad.p, nullptr) != VIGO_OK)
         return std::nan("");
     double cost = 0;
-    if (hipDeviceSynchronize() != hipSuccess || !dCost.download(&cost, 8) || !dGrad.download(grad, (size_t)n * 8)) return std::nan("");
+    if (!vigo_host::threadSync() || !dCost.download(&cost, 8) || !dGrad.download(grad, (size_t)n * 8)) return std::nan("");
     return cost;
 }
 
@@ -772,7 +908,7 @@ bool bsplineTraj::termCost(int term, const Eigen::MatrixXd& controlPoints, doubl
                        (const double*)dW.p, (double*)dCost.p, (double*)dGrad.p, nullptr) != VIGO_OK)
         return false;
     std::vector<double> g(n);
-    if (hipDeviceSynchronize() != hipSuccess || !dCost.download(&cost, 8) || !dGrad.download(g.data(), (size_t)n * 8)) return false;
+    if (!vigo_host::threadSync() || !dCost.download(&cost, 8) || !dGrad.download(g.data(), (size_t)n * 8)) return false;
     std::memcpy(gradient.data() + 3 * bsplineDegree, g.data(), (size_t)n * 8);
     return true;
 }
@@ -831,15 +967,18 @@ void bsplineTraj::reboundBegin(Rebound& r) {
     r.wo0 = this->weightDynamicObstacle_;
 }
 
+// leaving the loop: the weights the loop doubled are restored (BT.cpp:629-630, :635-636, :651-652)
+void bsplineTraj::reboundFinish(Rebound& r, bool ok) {
+    this->weightDistance_ = r.w0;
+    this->weightDynamicObstacle_ = r.wo0;
+    r.done = true;
+    r.ok = ok;
+}
+
 // the body of the while loop of BT.cpp:619-681, one pass
 void bsplineTraj::reboundStep(Rebound& r, bool hasCollision, bool hasDynamicCollision, bool timedOut) {
     r.needOptimize = false;
-    auto finish = [&](bool ok) {
-        this->weightDistance_ = r.w0;
-        this->weightDynamicObstacle_ = r.wo0;
-        r.done = true;
-        r.ok = ok;
-    };
+    auto finish = [&](bool ok) { this->reboundFinish(r, ok); };
     if (!hasCollision && !hasDynamicCollision) { finish(true); return; }
     if (timedOut) { cout << "[BsplineTraj]: Optimization timeout." << endl; finish(false); return; }
     std::vector<std::vector<Eigen::Vector3d>> tempAstarPaths;
@@ -923,6 +1062,85 @@ std::vector<bool> bsplineTraj::makePlanBatch(const std::vector<bsplineTraj*>& pl
     // step 4: rebound loops.  The 30 ms budget of BT.cpp:633 is per makePlan() call in the
     // reference; a batch keeps it per round so one slow planner cannot starve the others.
     const bool timing = getenv("VIGO_FACADE_TIMING") != nullptr;
+    if (deviceResidentRebound()) {
+        // The loop runs on the device between two A* calls (vigo_rebound_rounds): gates, success exit, isReguideRequired,
+        // weight doubling and re-solve are queued for up to kRounds rounds without a host round trip; the host only sees
+        // the planners that are done, need A* (re-guide, or failCount >= 4) or ran out of queued rounds.
+        const int kRounds = 4;   // failCount reaches 4 after at most four device rounds: then every round needs A*
+        const double t0 = wallSeconds();
+        const double budget = 0.03 * std::max<size_t>(1, active.size());
+        while (!active.empty()) {
+            const double tr0 = wallSeconds();
+            // one device batch per group of planners the lead's handle state fits
+            std::vector<bool> grouped(active.size(), false);
+            std::vector<uint8_t> devOk(active.size(), 0);
+            for (size_t a = 0; a < active.size(); ++a) {
+                if (grouped[a]) continue;
+                std::vector<bsplineTraj*> grp;
+                std::vector<Rebound*> grb;
+                std::vector<size_t> members;
+                for (size_t b = a; b < active.size(); ++b)
+                    if (!grouped[b] && active[a]->sameBatchKey(*active[b])) {
+                        grp.push_back(active[b]);
+                        grb.push_back(&rb[activeIdx[b]]);
+                        members.push_back(b);
+                        grouped[b] = true;
+                    }
+                const bool ok = deviceRounds(grp, grb, kRounds);
+                for (size_t m : members) devOk[m] = ok ? 1 : 0;
+            }
+            const double tr1 = wallSeconds();
+            const bool timedOut = wallSeconds() - t0 > budget;
+            if (timedOut) {
+                // BT.cpp:633-637: out of time.  The reference tests the budget right after the gates: the planners still
+                // in the loop get one more gate (a trajectory that is collision free by now succeeds), the rest fail.
+                std::vector<bool> g2(active.size(), false);
+                for (size_t a = 0; a < active.size(); ++a) {
+                    if (g2[a]) continue;
+                    std::vector<bsplineTraj*> grp;
+                    std::vector<size_t> members;
+                    for (size_t b = a; b < active.size(); ++b)
+                        if (!g2[b] && active[a]->sameBatchKey(*active[b])) { grp.push_back(active[b]); members.push_back(b); g2[b] = true; }
+                    std::vector<uint8_t> col, dyn;
+                    gateBatch(grp, col, dyn);
+                    for (size_t m = 0; m < members.size(); ++m) {
+                        Rebound& r = rb[activeIdx[members[m]]];
+                        if (r.devStatus == VIGO_RB_DONE) continue;
+                        r.devStatus = (!col[m] && !dyn[m] && devOk[members[m]]) ? VIGO_RB_DONE : VIGO_RB_NEEDS_HOST;
+                        r.gateStatic = col[m] != 0;
+                        r.gateDynamic = dyn[m] != 0;
+                    }
+                }
+            }
+            size_t nHost = 0;
+            for (size_t a = 0; a < active.size(); ++a) nHost += rb[activeIdx[a]].devStatus == VIGO_RB_NEEDS_HOST ? 1 : 0;
+            parallelFor(active.size(), [&](size_t a) {
+                Rebound& r = rb[activeIdx[a]];
+                bsplineTraj* p = active[a];
+                if (!devOk[a]) { p->reboundFinish(r, false); return; }             // no device: nothing to plan with
+                if (r.devStatus == VIGO_RB_DONE) p->reboundFinish(r, true);          // BT.cpp:628-631
+                else if (r.devStatus == VIGO_RB_NEEDS_HOST) p->reboundStep(r, r.gateStatic, r.gateDynamic, timedOut);   // A* and the rest of the pass
+                // (still active: its next step is the gate, or the optimize() the device left for the next call)
+            });
+            std::vector<bsplineTraj*> next;
+            std::vector<size_t> nextIdx;
+            for (size_t a = 0; a < active.size(); ++a) {
+                Rebound& r = rb[activeIdx[a]];
+                if (r.done) {
+                    result[activeIdx[a]] = r.ok;
+                    if (!r.ok) cout << "[BsplineTraj]: Fail because of optimizer not finding a solution." << endl;
+                } else {
+                    next.push_back(active[a]);
+                    nextIdx.push_back(activeIdx[a]);
+                }
+            }
+            if (timing)
+                cout << "[BsplineTraj]:   device rounds (<= " << kRounds << ") of " << active.size() << ": " << (tr1 - tr0) * 1e3 << " ms, host step of "
+                     << nHost << " planners " << (wallSeconds() - tr1) * 1e3 << " ms, " << next.size() << " continue" << endl;
+            active.swap(next);
+            activeIdx.swap(nextIdx);
+        }
+    } else {
     double tr0 = wallSeconds();
     solveBatch(active);
     if (timing) cout << "[BsplineTraj]:   first solve of " << active.size() << ": " << (wallSeconds() - tr0) * 1e3 << " ms" << endl;
@@ -957,6 +1175,7 @@ std::vector<bool> bsplineTraj::makePlanBatch(const std::vector<bsplineTraj*>& pl
                  << " ms, solve of " << solve.size() << " " << (wallSeconds() - tr2) * 1e3 << " ms" << endl;
         active.swap(next);
         activeIdx.swap(nextIdx);
+    }
     }
     const double tp2 = wallSeconds();
     std::vector<uint8_t> okv(result.begin(), result.end());

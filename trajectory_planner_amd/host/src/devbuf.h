@@ -7,6 +7,20 @@
 
 namespace vigo_host {
 
+// One non-blocking HIP stream per host thread: the facades bind the handle they drive to it (vigo_set_stream), stage
+// their copies on it and wait on it alone, so two host threads planning two batches overlap on the device instead of
+// meeting in hipDeviceSynchronize().  nullptr (the default stream) if the stream cannot be created.
+inline hipStream_t threadStream() {
+    static thread_local hipStream_t s = nullptr;
+    static thread_local bool tried = false;
+    if (!tried) {
+        tried = true;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+    }
+    return s;
+}
+inline bool threadSync() { return hipStreamSynchronize(threadStream()) == hipSuccess; }
+
 // RAII device buffer; every HIP failure is reported to the caller as `false`
 struct DevBuf {
     void* p = nullptr;
@@ -21,7 +35,8 @@ struct DevBuf {
             if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return false;
             n = bytes;
         }
-        return bytes == 0 || hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+        // (pageable source: staged by the runtime before the call returns; ordered with the thread's stream)
+        return bytes == 0 || hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, threadStream()) == hipSuccess;
     }
     bool alloc(size_t bytes) {
         if (bytes <= n && p) return true;
@@ -32,7 +47,9 @@ struct DevBuf {
         n = bytes;
         return true;
     }
-    bool download(void* dst, size_t bytes) const { return hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost) == hipSuccess; }
+    bool download(void* dst, size_t bytes) const {
+        return hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, threadStream()) == hipSuccess && threadSync();
+    }
 };
 
 // thread-lifetime staging buffer (declare `static thread_local`): grows on demand, is reused by every later call

@@ -54,6 +54,8 @@ bool polyTrajOctomap::syncDevice() {
         dev_ = nullptr;
         return false;
     }
+    // launches and staging copies of this call go to the calling thread's stream
+    if (vigo_set_stream(dev_, vigo_host::threadStream()) != VIGO_OK) return false;
     if (mapVersion_ != map_->version) {
         const double o[3] = {map_->origin()(0), map_->origin()(1), map_->origin()(2)};
         if (vigo_set_grid_host(dev_, map_->nx(), map_->ny(), map_->nz(), o, map_->getRes(), map_->voxels().data()) != VIGO_OK) return false;

@@ -4,13 +4,16 @@
 #include <trajectory_planner/bsplineTraj.h>
 #include <trajectory_planner/polyTrajOctomap.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <iostream>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <cstring>
 #include <set>
+#include <thread>
 
 using trajPlanner::bsplineTraj;
 
@@ -173,32 +176,98 @@ int main() {
     }
 
     // ---- application-level rate: 1024 planners through updatePathBatch + makePlanBatch (host A*, guide
-    //      assignment and bookkeeping included), reported, not gated ----
+    //      assignment and bookkeeping included), reported, not gated — once with the rebound loop resident on the
+    //      device between A* calls (vigo_rebound_rounds, the default) and once driven round by round from the host
+    //      (the round-1 path): control points, success flags and solver status must be identical ----
     {
         const int NP = 1024;
-        std::vector<std::unique_ptr<bsplineTraj>> owners;
-        std::vector<bsplineTraj*> ps;
+        struct Run { std::vector<std::unique_ptr<bsplineTraj>> owners; std::vector<bsplineTraj*> ps; std::vector<bool> res; double msU = 0, msP = 0; };
         std::vector<nav_msgs::Path> paths;
         for (int i = 0; i < NP; ++i) {
-            owners.emplace_back(new bsplineTraj(makeParams()));
-            owners.back()->setMap(map);
-            owners.back()->updateMaxVel(2.0);
-            owners.back()->updateMaxAcc(3.0);
-            ps.push_back(owners.back().get());
             const double y = -2.6 + 5.2 * (i % 97) / 96.0, tilt = 0.4 * ((i * 37) % 11 - 5) / 5.0;
             paths.push_back(straight(-3.0, y, 3.0, y + tilt, 1.0, 0.25));
         }
-        const auto t0 = std::chrono::steady_clock::now();
-        std::vector<bool> up = bsplineTraj::updatePathBatch(ps, paths, std::vector<std::vector<Eigen::Vector3d>>(NP, cond));
-        const auto t1 = std::chrono::steady_clock::now();
-        std::vector<bool> res = bsplineTraj::makePlanBatch(ps);
-        const auto t2 = std::chrono::steady_clock::now();
-        int good = 0, clean = 0;
-        for (int i = 0; i < NP; ++i) { good += res[i]; if (res[i] && ps[i]->isCurrTrajValid()) ++clean; }
-        const double msU = std::chrono::duration<double, std::milli>(t1 - t0).count(), msP = std::chrono::duration<double, std::milli>(t2 - t1).count();
-        std::printf("INFO 1024 planners: updatePathBatch %.2f ms, makePlanBatch %.2f ms (%.0f plans/s end to end), %d planned, %d verified collision free\n",
-                    msU, msP, NP / ((msU + msP) * 1e-3), good, clean);
+        auto construct = [&](Run& R) {
+            for (int i = 0; i < NP; ++i) {
+                R.owners.emplace_back(new bsplineTraj(makeParams()));
+                R.owners.back()->setMap(map);
+                R.owners.back()->updateMaxVel(2.0);
+                R.owners.back()->updateMaxAcc(3.0);
+                R.ps.push_back(R.owners.back().get());
+            }
+        };
+        auto plan = [&](bool deviceLoop, Run& R) {
+            bsplineTraj::setDeviceResidentRebound(deviceLoop);
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<bool> up = bsplineTraj::updatePathBatch(R.ps, paths, std::vector<std::vector<Eigen::Vector3d>>(NP, cond));
+            const auto t1 = std::chrono::steady_clock::now();
+            R.res = bsplineTraj::makePlanBatch(R.ps);
+            const auto t2 = std::chrono::steady_clock::now();
+            bsplineTraj::setDeviceResidentRebound(true);
+            R.msU = std::chrono::duration<double, std::milli>(t1 - t0).count();
+            R.msP = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        };
+        auto runBatch = [&](bool deviceLoop, Run& R) { construct(R); plan(deviceLoop, R); };
+        Run warm, dev, host;
+        runBatch(true, warm);                      // first use of the kernels and buffers of this size
+        runBatch(true, dev);
+        runBatch(false, host);
+        int good = 0, clean = 0, same = 0;
+        for (int i = 0; i < NP; ++i) {
+            good += dev.res[i];
+            if (dev.res[i] && dev.ps[i]->isCurrTrajValid()) ++clean;
+            const Eigen::MatrixXd a = dev.ps[i]->getControlPoints(), b = host.ps[i]->getControlPoints();
+            bool eq = dev.res[i] == host.res[i] && a.cols() == b.cols() && dev.ps[i]->getLastSolverStatus() == host.ps[i]->getLastSolverStatus();
+            if (eq) eq = std::memcmp(a.data(), b.data(), sizeof(double) * 3 * a.cols()) == 0;
+            same += eq;
+            if (!eq && same + 5 > i) {
+                double worst = 0;
+                for (int c = 0; c < a.cols() && c < b.cols(); ++c) for (int r = 0; r < 3; ++r) worst = std::fmax(worst, std::fabs(a(r, c) - b(r, c)));
+                std::printf("INFO mismatch planner %d: success %d/%d, solver status %d/%d, max |diff| %.3e\n", i, (int)dev.res[i], (int)host.res[i],
+                            dev.ps[i]->getLastSolverStatus(), host.ps[i]->getLastSolverStatus(), worst);
+            }
+        }
+        std::printf("INFO 1024 planners, rebound loop on the device: updatePathBatch %.2f ms, makePlanBatch %.2f ms (%.0f plans/s end to end), %d planned, %d verified collision free\n",
+                    dev.msU, dev.msP, NP / ((dev.msU + dev.msP) * 1e-3), good, clean);
+        std::printf("INFO 1024 planners, rebound loop driven by the host: updatePathBatch %.2f ms, makePlanBatch %.2f ms (%.0f plans/s end to end)\n",
+                    host.msU, host.msP, NP / ((host.msU + host.msP) * 1e-3));
         CHECK(good >= NP * 8 / 10 && clean == good, "1024-planner batch: every success is collision free");
+        CHECK(same == NP, "device-resident rebound loop == host-driven loop (control points, success, solver status, bit for bit)");
+        // two batches in flight: two host threads, each planning its own 1024 planners (own handles and staging buffers)
+        {
+            Run A, B2, wA, wB;
+            construct(A);
+            construct(B2);
+            construct(wA);
+            construct(wB);
+            // (a planner service keeps its threads: each worker first plans a warm-up batch, so its thread-local stream
+            // and staging buffers exist, then both start the timed batch together)
+            std::atomic<int> ready{0};
+            std::chrono::steady_clock::time_point tStart[2], tEnd[2];
+            auto worker = [&](int id, Run& warmRun, Run& timed) {
+                plan(true, warmRun);
+                ready.fetch_add(1);
+                while (ready.load() < 2) std::this_thread::yield();
+                tStart[id] = std::chrono::steady_clock::now();
+                plan(true, timed);
+                tEnd[id] = std::chrono::steady_clock::now();
+            };
+            std::thread ta(worker, 0, std::ref(wA), std::ref(A));
+            std::thread tb(worker, 1, std::ref(wB), std::ref(B2));
+            ta.join();
+            tb.join();
+            const double ms = std::chrono::duration<double, std::milli>(std::max(tEnd[0], tEnd[1]) - std::min(tStart[0], tStart[1])).count();
+            int okBoth = 0, eqBoth = 0;
+            for (int i = 0; i < NP; ++i) {
+                okBoth += A.res[i] && B2.res[i];
+                const Eigen::MatrixXd a = A.ps[i]->getControlPoints(), b = dev.ps[i]->getControlPoints(), c = B2.ps[i]->getControlPoints();
+                eqBoth += a.cols() == b.cols() && c.cols() == b.cols() && std::memcmp(a.data(), b.data(), sizeof(double) * 3 * a.cols()) == 0 &&
+                          std::memcmp(c.data(), b.data(), sizeof(double) * 3 * c.cols()) == 0;
+            }
+            std::printf("INFO two batches of 1024 in flight (two host threads, each updatePathBatch + makePlanBatch): %.2f ms, %.0f plans/s, %d planned in both\n",
+                        ms, 2 * NP / (ms * 1e-3), okBoth);
+            CHECK(eqBoth == NP, "concurrent batches give the single-batch control points");
+        }
     }
 
     // ---- polyTrajOctomap checker ----
@@ -333,7 +402,7 @@ int main() {
         const int rounds = fz ? std::atoi(fz) : 3;
         unsigned long long st = 0x9E3779B97F4A7C15ull;
         auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0; };
-        int planned = 0, total = 0, dirty = 0, clipped = 0, polyValid = 0, polyTotal = 0, polyDirty = 0;
+        int planned = 0, total = 0, dirty = 0, clipped = 0, polyValid = 0, polyTotal = 0, polyDirty = 0, loopMismatch = 0, obstaclePlans = 0;
         for (int round = 0; round < rounds; ++round) {
             auto m = std::make_shared<mapManager::occMap>(128, 128, 40, Eigen::Vector3d(-6.4, -6.4, -0.5), 0.1);
             const int nb = 3 + (int)(rnd() * 10);
@@ -353,32 +422,58 @@ int main() {
                 return false;
             };
             const int NPR = 40 + (int)(rnd() * 60);
-            std::vector<std::unique_ptr<bsplineTraj>> owners;
-            std::vector<bsplineTraj*> ps;
+            std::vector<std::unique_ptr<bsplineTraj>> owners, twins;
+            std::vector<bsplineTraj*> ps, ps2;
             std::vector<nav_msgs::Path> paths;
             std::vector<double> vels, readyVel;
+            std::vector<std::vector<std::vector<Eigen::Vector3d>>> obsOf;   // per planner: {pos, vel, size} or empty
             for (int i = 0; i < NPR; ++i) {
                 double x0, y0, x1, y1;
                 if (!freePoint(x0, y0) || !freePoint(x1, y1) || std::hypot(x1 - x0, y1 - y0) < 2.0) continue;
+                // every planner has a twin with the same inputs: the twins run the rebound loop from the host
                 owners.emplace_back(new bsplineTraj(makeParams()));
-                owners.back()->setMap(m);
+                twins.emplace_back(new bsplineTraj(makeParams()));
                 vels.push_back(1.0 + 2.0 * rnd());
-                owners.back()->updateMaxVel(vels.back());
-                owners.back()->updateMaxAcc(2.0 + 2.0 * rnd());
+                const double acc = 2.0 + 2.0 * rnd();
+                for (bsplineTraj* q : {owners.back().get(), twins.back().get()}) {
+                    q->setMap(m);
+                    q->updateMaxVel(vels.back());
+                    q->updateMaxAcc(acc);
+                }
                 if (i % 3 == 0) {
                     const double f = rnd();
                     std::vector<Eigen::Vector3d> op{Eigen::Vector3d(x0 + (x1 - x0) * f + 0.8 * (rnd() - 0.5), y0 + (y1 - y0) * f + 0.8 * (rnd() - 0.5), 1.0)};
                     std::vector<Eigen::Vector3d> ov{Eigen::Vector3d(rnd() - 0.5, rnd() - 0.5, 0.0)};
                     std::vector<Eigen::Vector3d> os{Eigen::Vector3d(0.4 + 0.4 * rnd(), 0.4 + 0.4 * rnd(), 1.5)};
-                    owners.back()->updateDynamicObstacles(op, ov, os);
+                    obsOf.push_back({op, ov, os});
+                } else {
+                    obsOf.push_back({});
                 }
                 ps.push_back(owners.back().get());
+                ps2.push_back(twins.back().get());
                 paths.push_back(straight(x0, y0, x1, y1, 1.0, 0.25));
             }
+            // (updatePath clear()s the obstacles, BT.cpp:393-401: they are set after it, like src/bspline_node.cpp does)
             std::vector<bool> up = bsplineTraj::updatePathBatch(ps, paths, std::vector<std::vector<Eigen::Vector3d>>(ps.size(), cond));
-            std::vector<bsplineTraj*> ready;
-            for (size_t i = 0; i < ps.size(); ++i) if (up[i]) { ready.push_back(ps[i]); readyVel.push_back(vels[i]); }
+            std::vector<bool> up2 = bsplineTraj::updatePathBatch(ps2, paths, std::vector<std::vector<Eigen::Vector3d>>(ps2.size(), cond));
+            std::vector<bsplineTraj*> ready, ready2;
+            for (size_t i = 0; i < ps.size(); ++i) {
+                if (!obsOf[i].empty()) {
+                    ps[i]->updateDynamicObstacles(obsOf[i][0], obsOf[i][1], obsOf[i][2]);
+                    ps2[i]->updateDynamicObstacles(obsOf[i][0], obsOf[i][1], obsOf[i][2]);
+                }
+                if (up[i] && up2[i]) { ready.push_back(ps[i]); ready2.push_back(ps2[i]); readyVel.push_back(vels[i]); }
+            }
             std::vector<bool> res = bsplineTraj::makePlanBatch(ready);
+            bsplineTraj::setDeviceResidentRebound(false);
+            std::vector<bool> resHost = bsplineTraj::makePlanBatch(ready2);
+            bsplineTraj::setDeviceResidentRebound(true);
+            for (size_t i = 0; i < ready.size(); ++i) {
+                const Eigen::MatrixXd a = ready[i]->getControlPoints(), b = ready2[i]->getControlPoints();
+                const bool eq = res[i] == resHost[i] && a.cols() == b.cols() && std::memcmp(a.data(), b.data(), sizeof(double) * 3 * a.cols()) == 0;
+                loopMismatch += eq ? 0 : 1;
+                obstaclePlans += ready[i]->hasDynamicObstacles() ? 1 : 0;
+            }
             for (size_t i = 0; i < ready.size(); ++i) {
                 ++total;
                 if (!res[i]) continue;
@@ -449,6 +544,8 @@ int main() {
         std::printf("INFO stress: %d rounds; bsplineTraj %d of %d planned, %d failed the host gate, %d clip a voxel between gate samples; polyTrajOctomap %d of %d valid, %d dirty\n",
                     rounds, planned, total, dirty, clipped, polyValid, polyTotal, polyDirty);
         CHECK(dirty == 0 && planned > 0, "stress: every bsplineTraj success is collision free on the host copy of the map");
+        std::printf("INFO stress: %d plans carried dynamic obstacles; device-resident vs host-driven rebound loop: %d of %d differ\n", obstaclePlans, loopMismatch, total);
+        CHECK(loopMismatch == 0, "stress: device-resident rebound loop == host-driven loop on every planner (bit for bit)");
         CHECK(polyDirty == 0, "stress: every valid polyTrajOctomap plan keeps its poses out of occupied voxels");
     }
 
