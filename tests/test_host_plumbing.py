@@ -291,3 +291,44 @@ def test_minsnap_corridor_constraints_hold_and_tighten(host):
     rc = host.vigo_host_minsnap(len(wp), wp.ctypes.data_as(_dp), 7, 4, 4, 1.0, cor.ctypes.data_as(_dp), 8.0,
                                 co.ctypes.data_as(_dp), kn.ctypes.data_as(_dp))
     assert rc == -1
+
+
+def test_facade_sources_compile_against_the_reference_surface_only(tmp_path):
+    """`make strict` (host/Makefile): the planner sources with -DVIGO_WITH_ROS against host/test/strict_api/, whose
+    mapManager::occMap declares the four methods the reference calls and nothing else — and a source that reaches for
+    the dense stand-in's members does not compile there."""
+    import subprocess
+    host = os.path.join(ROOT, "trajectory_planner_amd", "host")
+    r = subprocess.run(["make", "-C", host, "strict", "-B"], capture_output=True, text=True)
+    assert r.returncode == 0 and "strict: 6 planner sources" in r.stdout, r.stdout + r.stderr
+    bad = tmp_path / "bad.cpp"
+    bad.write_text('#include <trajectory_planner/bsplineTraj.h>\n'
+                   'unsigned long long f(mapManager::occMap& m) { return m.version + m.voxels().size(); }\n')
+    flags = ["-std=c++14", "-fsyntax-only", "-DVIGO_WITH_ROS", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(host, "test", "strict_api"),
+             "-I", os.path.join(host, "include"), "-I", "/opt/rocm/include"]
+    r = subprocess.run(["g++"] + flags + [str(bad)], capture_output=True, text=True)
+    assert r.returncode != 0 and "version" in r.stderr
+    ok = tmp_path / "ok.cpp"
+    ok.write_text('#include <trajectory_planner/bsplineTraj.h>\n'
+                  'bool f(mapManager::occMap& m, const Eigen::Vector3d& p) { return m.isInflatedOccupied(p) || m.isUnknown(p) || m.getRes() > 0; }\n')
+    assert subprocess.run(["g++"] + flags + [str(ok)], capture_output=True, text=True).returncode == 0
+
+
+def test_map_adapter_rasterises_through_the_four_public_methods():
+    """mapAdapter::rasterise (what a map_manager build uploads): voxel centres of a box asked isInflatedOccupied /
+    isUnknown give back the dense map's own bits, inside the map and beyond its rim (outside = occupied and unknown)"""
+    import ctypes as C
+    L = C.CDLL(os.path.join(ROOT, "trajectory_planner_amd", "lib", "libtrajectory_planner_vigo.so"))
+    dp = C.POINTER(C.c_double)
+    L.vigo_host_rasterise_check.restype = C.c_longlong
+    L.vigo_host_rasterise_check.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_double, C.c_void_p, dp, dp, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(3)
+    vox = (rng.random((40, 33, 17)) < 0.2).astype(np.uint8) * 5 + (rng.random((40, 33, 17)) < 0.1).astype(np.uint8) * 2
+    origin = np.array([-2.0, -1.6, 0.2])
+    dims = (C.c_int * 3)()
+    for lo, hi, want in (([-2.0, -1.6, 0.2], [2.0, 1.7, 1.9], (40, 33, 17)),       # exactly the map
+                         ([-2.35, -1.0, 0.0], [0.5, 2.4, 2.5], (29, 34, 25))):      # a box that sticks out of it
+        lo_a, hi_a = np.array(lo), np.array(hi)
+        bad = L.vigo_host_rasterise_check(40, 33, 17, origin.ctypes.data_as(dp), 0.1, vox.ctypes.data_as(C.c_void_p),
+                                          lo_a.ctypes.data_as(dp), hi_a.ctypes.data_as(dp), dims)
+        assert bad == 0 and tuple(dims) == want, (bad, tuple(dims))

@@ -15,6 +15,7 @@
 #define BSPLINETRAJ_H
 #include <trajectory_planner/bspline.h>
 #include <trajectory_planner/compat.h>
+#include <trajectory_planner/mapAdapter.h>
 #include <trajectory_planner/path_search/astarOcc.h>
 #include <trajectory_planner/utils.h>
 
@@ -61,7 +62,8 @@ private:
 
     // device
     vigo_context* dev_ = nullptr;
-    uint64_t mapVersion_ = 0;
+    uint64_t mapStamp_ = 0;            // mapAdapter's memo of the snapshot this planner's handle holds (0 = none)
+    mapRegion mapRegion_;
     int lastStatus_ = 0;
     bool syncDevice();   // params + map snapshot -> handle; false when no GPU / HIP failure
 
@@ -84,6 +86,10 @@ public:
     void init(const ros::NodeHandle& nh);
     void initParam();
     void setMap(const std::shared_ptr<mapManager::occMap>& map);
+    /* not in the reference: the box of the map the device snapshot covers (needed for a map type that offers no bulk
+     * access, see mapAdapter.h; ignored by the in-tree dense map) and the request to re-snapshot a map that changed */
+    void setMapRegion(const Eigen::Vector3d& boxMin, const Eigen::Vector3d& boxMax);
+    void refreshMap();
     void updateMaxVel(double maxVel);
     void updateMaxAcc(double maxAcc);
     bool inputPathCheck(const nav_msgs::Path& path, nav_msgs::Path& adjustedPath, double dt, double& finalTime);

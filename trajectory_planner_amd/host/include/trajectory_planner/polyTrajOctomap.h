@@ -13,6 +13,7 @@
 #ifndef POLYTRAJOCTOMAP_H
 #define POLYTRAJOCTOMAP_H
 #include <trajectory_planner/compat.h>
+#include <trajectory_planner/mapAdapter.h>
 #include <trajectory_planner/polyTrajSolver.h>
 #include <trajectory_planner/utils.h>
 
@@ -41,7 +42,8 @@ private:
     double initVel_[3] = {0, 0, 0}, initAcc_[3] = {0, 0, 0};
     std::shared_ptr<mapManager::occMap> map_;
     vigo_context* dev_ = nullptr;
-    uint64_t mapVersion_ = 0;
+    uint64_t mapStamp_ = 0;             // mapAdapter's memo of the snapshot the handle holds (0 = none)
+    mapRegion mapRegion_;
     int lastIterations_ = 0;
     bool syncDevice();
     bool sweepPoints(const std::vector<pose>& pts, std::vector<uint8_t>& flags);
@@ -80,7 +82,11 @@ public:
     void makePlanCorridorConstraint(std::vector<pose>& trajectory, double delT);
     void insertWaypoint(const std::set<int>& seg);                     // PO.cpp:178-186
     /* re-snapshot the map on the next device call (the reference re-fetches /octomap_binary, PO.cpp:133-145) */
-    void updateMap() { mapVersion_ = 0; }
+    void updateMap() { mapStamp_ = 0; }
+    /* not in the reference: the box of the map the device snapshot covers (mapAdapter.h; ignored by the dense map) */
+    void setMapRegion(const Eigen::Vector3d& boxMin, const Eigen::Vector3d& boxMax) {
+        mapRegion_.set = true; mapRegion_.boxMin = boxMin; mapRegion_.boxMax = boxMax; mapStamp_ = 0;
+    }
 
     bool checkCollision(const pose& p);                                         // box sweep, PO.cpp:547-568
     bool checkCollisionPoint(const pose& p, bool ignoreUnknown = false);        // PO.cpp:571-595

@@ -106,8 +106,17 @@ void bsplineTraj::setMap(const std::shared_ptr<mapManager::occMap>& map) {
     int maxGridY = 2 * int(this->maxObstacleSize_(1) / this->map_->getRes());
     int maxGridZ = 2 * int(this->maxObstacleSize_(2) / this->map_->getRes());
     this->pathSearch_->initGridMap(map, Eigen::Vector3i(maxGridX, maxGridY, maxGridZ), this->minHeight_, this->maxHeight_);
-    this->mapVersion_ = 0;  // force a new device snapshot
+    this->mapStamp_ = 0;  // force a new device snapshot
 }
+
+void bsplineTraj::setMapRegion(const Eigen::Vector3d& boxMin, const Eigen::Vector3d& boxMax) {
+    this->mapRegion_.set = true;
+    this->mapRegion_.boxMin = boxMin;
+    this->mapRegion_.boxMax = boxMax;
+    this->mapStamp_ = 0;
+}
+
+void bsplineTraj::refreshMap() { this->mapStamp_ = 0; }
 
 void bsplineTraj::updateMaxVel(double maxVel) { this->maxVel_ = maxVel; }
 void bsplineTraj::updateMaxAcc(double maxAcc) { this->maxAcc_ = maxAcc; }
@@ -148,7 +157,7 @@ bool bsplineTraj::sameBatchKey(const bsplineTraj& o) const {
     return std::memcmp(&a, &b, sizeof(a)) == 0;
 }
 
-// handle creation, parameter push and (re)snapshot of the map when its version moved
+// handle creation, parameter push and (re)snapshot of the map when it changed (mapAdapter)
 bool bsplineTraj::syncDevice() {
     if (!dev_) {
         if (vigo_create(&dev_, 0) != VIGO_OK) {
@@ -163,12 +172,7 @@ bool bsplineTraj::syncDevice() {
     vigo_params_t P;
     this->fillParams(&P);
     if (vigo_set_params(dev_, &P) != VIGO_OK) return false;
-    if (map_ && mapVersion_ != map_->version) {
-        const double o[3] = {map_->origin()(0), map_->origin()(1), map_->origin()(2)};
-        if (vigo_set_grid_host(dev_, map_->nx(), map_->ny(), map_->nz(), o, map_->getRes(), map_->voxels().data()) != VIGO_OK)
-            return false;
-        mapVersion_ = map_->version;
-    }
+    if (map_ && !mapAdapter::uploadSnapshot(dev_, map_, mapRegion_, mapStamp_)) return false;
     return true;
 }
 
@@ -879,7 +883,7 @@ double bsplineTraj::solverCostFunction(void* func_data, const double* x, double*
 bool bsplineTraj::termCost(int term, const Eigen::MatrixXd& controlPoints, double& cost, Eigen::MatrixXd& gradient) {
     cost = 0;
     const int N = controlPoints.cols();
-    gradient.resize(3, N);
+    gradient = Eigen::MatrixXd::Zero(3, N);
     if (N < 7 || N > VIGO_MAX_CTRL_POINTS || (int)optData_.guidePoints.size() < N || !syncDevice()) return false;
     std::vector<double> gpv, obs, w(4, 0.0);
     w[term] = 1.0;

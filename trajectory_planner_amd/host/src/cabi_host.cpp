@@ -1,6 +1,9 @@
 // cabi_host.cpp — small extern "C" entry points of libtrajectory_planner_vigo.so so the Python
 // tests can exercise the host-side pieces that have no GPU part (the .bt reader and the min-snap
 // QP) with ctypes.  Not part of include/vigo.h (that is the device ABI).
+#ifdef VIGO_WITH_ROS
+#error "tools of the in-tree dense map (standin/dense_occmap.h): not part of a build against map_manager"
+#endif
 #include <trajectory_planner/octomapBt.h>
 #include <trajectory_planner/polyTrajOctomap.h>
 #include <trajectory_planner/polyTrajSolver.h>
@@ -106,3 +109,31 @@ int vigo_host_poly_plan(int nx, int ny, int nz, const double* origin, double res
 }
 
 }  // extern "C"
+
+// mapAdapter::rasterise (the generic route: four public map methods only) over the whole box of a dense map must give
+// back that map's inflated-occupied and unknown bits.  Returns the number of differing voxels (0 = agreement), -1 on
+// failure; dims_out receives the rasterised grid's extents.
+extern "C" long long vigo_host_rasterise_check(int nx, int ny, int nz, const double* origin, double res, const unsigned char* voxels,
+                                               const double* box_min, const double* box_max, int* dims_out) {
+    auto map = std::make_shared<mapManager::occMap>(nx, ny, nz, Eigen::Vector3d(origin[0], origin[1], origin[2]), res);
+    std::memcpy(map->voxels().data(), voxels, (size_t)nx * ny * nz);
+    trajPlanner::mapRegion region;
+    region.set = true;
+    region.boxMin = Eigen::Vector3d(box_min[0], box_min[1], box_min[2]);
+    region.boxMax = Eigen::Vector3d(box_max[0], box_max[1], box_max[2]);
+    std::vector<uint8_t> vox;
+    int dims[3];
+    double o[3];
+    if (!trajPlanner::mapAdapter::rasterise(*map, region, vox, dims, o)) return -1;
+    for (int a = 0; a < 3; ++a) dims_out[a] = dims[a];
+    long long bad = 0;
+    for (int ix = 0; ix < dims[0]; ++ix)
+        for (int iy = 0; iy < dims[1]; ++iy)
+            for (int iz = 0; iz < dims[2]; ++iz) {
+                const Eigen::Vector3d c(o[0] + (ix + 0.5) * res, o[1] + (iy + 0.5) * res, o[2] + (iz + 0.5) * res);
+                const unsigned want = map->byteAt(c);          // 0xFF outside the dense map: occupied and unknown
+                const unsigned got = vox[((size_t)ix * dims[1] + iy) * dims[2] + iz];
+                if ((got & 1u) != (want & 1u) || ((got >> 1) & 1u) != ((want >> 1) & 1u) || ((got >> 2) & 1u) != (got & 1u)) ++bad;
+            }
+    return bad;
+}

@@ -1,5 +1,8 @@
 // octomapBt.cpp — .bt reader (see the header for the format).  Two passes over the byte stream:
 // bounds, then fill.  Own implementation of the published octomap binary format.
+#ifdef VIGO_WITH_ROS
+#error "tools of the in-tree dense map (standin/dense_occmap.h): not part of a build against map_manager"
+#endif
 #include <trajectory_planner/octomapBt.h>
 #include <climits>
 

@@ -44,7 +44,7 @@ polyTrajOctomap::~polyTrajOctomap() {
 
 void polyTrajOctomap::setMap(const std::shared_ptr<mapManager::occMap>& map) {
     map_ = map;
-    mapVersion_ = 0;
+    mapStamp_ = 0;
 }
 
 bool polyTrajOctomap::syncDevice() {
@@ -56,12 +56,7 @@ bool polyTrajOctomap::syncDevice() {
     }
     // launches and staging copies of this call go to the calling thread's stream
     if (vigo_set_stream(dev_, vigo_host::threadStream()) != VIGO_OK) return false;
-    if (mapVersion_ != map_->version) {
-        const double o[3] = {map_->origin()(0), map_->origin()(1), map_->origin()(2)};
-        if (vigo_set_grid_host(dev_, map_->nx(), map_->ny(), map_->nz(), o, map_->getRes(), map_->voxels().data()) != VIGO_OK) return false;
-        mapVersion_ = map_->version;
-    }
-    return true;
+    return mapAdapter::uploadSnapshot(dev_, map_, mapRegion_, mapStamp_);
 }
 
 void polyTrajOctomap::updatePath(const nav_msgs::Path& path) {
@@ -123,18 +118,10 @@ bool polyTrajOctomap::checkCollision(const pose& p) {
 // PO.cpp:571-589 on the dense map (host: a single lookup)
 bool polyTrajOctomap::checkCollisionPoint(const pose& p, bool ignoreUnknown) {
     if (!map_) return true;
-    const float x = (float)p.x, y = (float)p.y, z = (float)p.z;
-    const double res = map_->getRes();
-    const Eigen::Vector3d o = map_->origin();
-    if (x < o(0) || x > o(0) + map_->nx() * res || y < o(1) || y > o(1) + map_->ny() * res || z < o(2) || z > o(2) + map_->nz() * res) return true;
-    const double rf = 1.0 / res;
-    const int kx = (int)std::floor(rf * (double)x) - (int)std::floor(o(0) / res + 0.5);
-    const int ky = (int)std::floor(rf * (double)y) - (int)std::floor(o(1) / res + 0.5);
-    const int kz = (int)std::floor(rf * (double)z) - (int)std::floor(o(2) / res + 0.5);
-    if (kx < 0 || ky < 0 || kz < 0 || kx >= map_->nx() || ky >= map_->ny() || kz >= map_->nz()) return !ignoreUnknown;
-    const unsigned v = map_->voxels()[((size_t)kx * map_->ny() + ky) * map_->nz() + kz];
-    if (v & 2u) return !ignoreUnknown;
-    return (v & 4u) != 0;
+    const unsigned v = mapAdapter::nodeBits(map_, mapRegion_, (float)p.x, (float)p.y, (float)p.z);   // pose2Octomap + search()
+    if (v & mapAdapter::kOutside) return true;                  // beyond getMetricMin/Max
+    if (v & mapAdapter::kUnknown) return !ignoreUnknown;        // no node there
+    return (v & mapAdapter::kOccupied) != 0;                    // isNodeOccupied
 }
 
 // PO.cpp:619-632

@@ -1,0 +1,3 @@
+// strict_api/nav_msgs/Path.h — ros::NodeHandle::getParam/setParam, ros::Time::now() and the message structs of the
+// facades' signatures (public data members named like the real messages).
+#include <trajectory_planner/standin/mini_ros.h>
