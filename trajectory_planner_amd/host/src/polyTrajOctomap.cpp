@@ -104,7 +104,7 @@ bool polyTrajOctomap::sweepPoints(const std::vector<pose>& pts, std::vector<uint
     bool ok = dP.upload(xyz.data(), xyz.size() * 8) && dF.alloc(pts.size());
     const double box[3] = {collisionBox_[0], collisionBox_[1], collisionBox_[2]};
     ok = ok && vigo_box_collision_points(dev_, (int64_t)pts.size(), (const double*)dP.p, box, mapRes_, (uint8_t*)dF.p) == VIGO_OK;
-    ok = ok && hipDeviceSynchronize() == hipSuccess && dF.download(flags.data(), pts.size());
+    ok = ok && dF.download(flags.data(), pts.size());
     if (!ok && dev_) cout << "[Trajectory Planner INFO]: device box sweep failed: " << vigo_last_error(dev_) << endl;
     return ok;
 }
@@ -286,67 +286,87 @@ void polyTrajOctomap::makePlan(std::vector<pose>& trajectory, double delT) {
     }
 }
 
+// makePlan() of many planners in lock-step, BOTH planning loops (adding waypoints PO.cpp:259-386, corridor constraint
+// PO.cpp:388-545).  Per round: the active planners are grouped by (waypoint count, mode) and every group's QPs are
+// ONE vigo_minsnap launch (corridor boxes for the corridor mode, none for the adding-waypoint mode, whose paths grow
+// as waypoints are inserted: the groups are re-formed every round); then every sample of every candidate trajectory
+// goes through ONE vigo_box_collision_points launch; the per-planner bookkeeping (shrink the corridor of the
+// colliding segments / insert waypoints there, iteration and time limits, the PWL fallback) stays on the host.
+// A path that outgrows the device QP (more than 11 waypoints) is solved by the host QP of the same algorithm
+// inside the same round.
 std::vector<bool> polyTrajOctomap::makePlanBatch(const std::vector<polyTrajOctomap*>& ps, std::vector<std::vector<pose>>& trajectories) {
     const size_t P = ps.size();
     std::vector<bool> result(P, false);
     trajectories.assign(P, {});
     if (P == 0) return result;
-    // planners the device path cannot take (adding-waypoint mode, installed polynomial, too many or too few
-    // waypoints, another polynomial degree) plan on their own
+    // planners the batch cannot take (installed polynomial, a single waypoint, another polynomial degree, another
+    // map or sweep geometry than the first planner's) plan on their own
     std::vector<size_t> grp;
     for (size_t i = 0; i < P; ++i) {
         polyTrajOctomap* p = ps[i];
         p->findValidTraj_ = false;
-        const bool batchable = !p->mode_ && p->extKnots_.empty() && p->path_.size() >= 2 && p->path_.size() <= 11 && p->polyDegree_ == 7 &&
-                               p->path_.size() == ps[0]->path_.size() && p->diffDegree_ == ps[0]->diffDegree_ &&
+        const bool batchable = p->extKnots_.empty() && p->path_.size() >= 2 && p->polyDegree_ == 7 && p->diffDegree_ == ps[0]->diffDegree_ &&
                                p->continuityDegree_ == ps[0]->continuityDegree_ && p->desiredVel_ == ps[0]->desiredVel_ &&
-                               p->corridorRes_ == ps[0]->corridorRes_ && p->map_ == ps[0]->map_;
+                               p->corridorRes_ == ps[0]->corridorRes_ && p->map_ == ps[0]->map_ && p->collisionBox_ == ps[0]->collisionBox_ &&
+                               p->mapRes_ == ps[0]->mapRes_;
         if (batchable) grp.push_back(i);
         else { p->makePlan(trajectories[i], p->delT_); result[i] = p->findValidTraj_; }
     }
     if (grp.empty()) return result;
     polyTrajOctomap* lead = ps[grp[0]];
     if (!lead->syncDevice()) return result;
-    const int W = (int)lead->path_.size(), K = W - 1, D = 8;
+    const int D = 8, kMaxDevWaypoints = 11;
     struct State { std::vector<double> corridor; int iters = 0; bool active = true; double t0 = 0; };
-    std::vector<State> st(grp.size());
-    for (size_t g = 0; g < grp.size(); ++g) {
+    const size_t G = grp.size();
+    std::vector<State> st(G);
+    for (size_t g = 0; g < G; ++g) {
         polyTrajOctomap* p = ps[grp[g]];
         p->setDefaultInit();
         p->trajSolver_.reset(new polyTrajSolver(p->polyDegree_, p->diffDegree_, p->continuityDegree_, p->desiredVel_));
         p->trajSolver_->updatePath(p->path_);
-        st[g].corridor.assign(K, p->initR_);
+        if (!p->mode_) st[g].corridor.assign(p->path_.size() - 1, p->initR_);
         st[g].t0 = nowSec();
     }
     static thread_local vigo_host::StagingBuf bWp, bCor, bCo, bKn, bSt, bPts, bFl;   // reused by every batch of this thread
-    const size_t G = grp.size();
-    bool ok = bWp.alloc(G * W * 24) && bCor.alloc(G * K * 8) && bCo.alloc(G * K * 3 * D * 8) && bKn.alloc(G * W * 8) && bSt.alloc(G * 4);
-    void *dWp = bWp.p, *dCor = bCor.p, *dCo = bCo.p, *dKn = bKn.p, *dSt = bSt.p, *dPts = nullptr, *dFl = nullptr;
-    std::vector<double> hWp, hCor, hCo(G * K * 3 * D);
-    std::vector<int32_t> hSt(G);
+    bool ok = true;
     while (ok) {
         std::vector<size_t> act;
         for (size_t g = 0; g < G; ++g) if (st[g].active) act.push_back(g);
         if (act.empty()) break;
-        const int T = (int)act.size();
-        hWp.clear(); hCor.clear();
-        for (size_t g : act) {
-            for (const pose& q : ps[grp[g]]->path_) { hWp.push_back(q.x); hWp.push_back(q.y); hWp.push_back(q.z); }
-            hCor.insert(hCor.end(), st[g].corridor.begin(), st[g].corridor.end());
-        }
-        ok = hipMemcpy(dWp, hWp.data(), hWp.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
-             hipMemcpy(dCor, hCor.data(), hCor.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
-             vigo_minsnap(lead->dev_, T, W, 7, lead->diffDegree_, lead->continuityDegree_, lead->desiredVel_, lead->corridorRes_, (const double*)dWp,
-                          (const double*)dCor, nullptr, (double*)dCo, (double*)dKn, (int32_t*)dSt) == VIGO_OK &&
-             hipDeviceSynchronize() == hipSuccess && hipMemcpy(hCo.data(), dCo, (size_t)T * K * 3 * D * 8, hipMemcpyDeviceToHost) == hipSuccess &&
-             hipMemcpy(hSt.data(), dSt, (size_t)T * 4, hipMemcpyDeviceToHost) == hipSuccess;
-        if (!ok) break;
-        // install the solutions (an infeasible corridor keeps the previous one, like the reference), sample, sweep all at once
-        std::vector<double> pts;
-        std::vector<size_t> first(T + 1, 0);
-        for (int a = 0; a < T; ++a) {
-            polyTrajOctomap* p = ps[grp[act[a]]];
-            if (hSt[a] == 0) {
+        // ---- the QPs: one launch per (waypoint count, mode) among the active planners ----
+        std::vector<bool> solved(G, false);
+        for (size_t a0 = 0; a0 < act.size() && ok; ++a0) {
+            const size_t g0 = act[a0];
+            if (solved[g0]) continue;
+            polyTrajOctomap* p0 = ps[grp[g0]];
+            const int W = (int)p0->path_.size(), K = W - 1;
+            if (W > kMaxDevWaypoints) {                       // beyond the device QP: the host QP, same algorithm
+                p0->trajSolver_->solve();
+                solved[g0] = true;
+                continue;
+            }
+            std::vector<size_t> members;
+            for (size_t a = a0; a < act.size(); ++a) {
+                polyTrajOctomap* q = ps[grp[act[a]]];
+                if (!solved[act[a]] && (int)q->path_.size() == W && q->mode_ == p0->mode_) { members.push_back(act[a]); solved[act[a]] = true; }
+            }
+            const int T = (int)members.size();
+            std::vector<double> hWp, hCor, hCo((size_t)T * K * 3 * D);
+            std::vector<int32_t> hSt(T);
+            for (size_t g : members) {
+                for (const pose& q : ps[grp[g]]->path_) { hWp.push_back(q.x); hWp.push_back(q.y); hWp.push_back(q.z); }
+                if (!p0->mode_) hCor.insert(hCor.end(), st[g].corridor.begin(), st[g].corridor.end());
+            }
+            ok = bWp.upload(hWp.data(), hWp.size() * 8) && (p0->mode_ || bCor.upload(hCor.data(), hCor.size() * 8)) &&
+                 bCo.alloc(hCo.size() * 8) && bKn.alloc((size_t)T * W * 8) && bSt.alloc((size_t)T * 4) &&
+                 vigo_minsnap(lead->dev_, T, W, 7, lead->diffDegree_, lead->continuityDegree_, lead->desiredVel_, lead->corridorRes_,
+                              (const double*)bWp.p, p0->mode_ ? nullptr : (const double*)bCor.p, nullptr, (double*)bCo.p, (double*)bKn.p,
+                              (int32_t*)bSt.p) == VIGO_OK &&
+                 bCo.download(hCo.data(), hCo.size() * 8) && bSt.download(hSt.data(), (size_t)T * 4);
+            if (!ok) break;
+            // install the solutions (an infeasible corridor keeps the previous one, like the reference)
+            for (int a = 0; a < T; ++a) {
+                if (hSt[a] != 0) continue;
                 std::vector<double> xs(K * D), ys(K * D), zs(K * D);
                 for (int sgm = 0; sgm < K; ++sgm)
                     for (int d = 0; d < D; ++d) {
@@ -354,9 +374,17 @@ std::vector<bool> polyTrajOctomap::makePlanBatch(const std::vector<polyTrajOctom
                         ys[sgm * D + d] = hCo[(((size_t)a * K + sgm) * 3 + 1) * D + d];
                         zs[sgm * D + d] = hCo[(((size_t)a * K + sgm) * 3 + 2) * D + d];
                     }
-                p->trajSolver_->installSolution(xs, ys, zs);
+                ps[grp[members[a]]]->trajSolver_->installSolution(xs, ys, zs);
             }
-            if (!p->trajSolver_->hasSolution()) {      // first corridor infeasible: not found (see makePlanCorridorConstraint)
+        }
+        if (!ok) break;
+        // ---- sample every candidate, sweep all samples at once ----
+        const int T = (int)act.size();
+        std::vector<double> pts;
+        std::vector<size_t> first(T + 1, 0);
+        for (int a = 0; a < T; ++a) {
+            polyTrajOctomap* p = ps[grp[act[a]]];
+            if (!p->trajSolver_->hasSolution()) {      // nothing to sample (first corridor infeasible, degenerate path): not found
                 trajectories[grp[act[a]]].clear();
                 st[act[a]].active = false;
                 first[a + 1] = pts.size() / 3;
@@ -367,16 +395,14 @@ std::vector<bool> polyTrajOctomap::makePlanBatch(const std::vector<polyTrajOctom
             first[a + 1] = pts.size() / 3;
         }
         const size_t M = pts.size() / 3;
-        ok = bPts.alloc(M * 24) && bFl.alloc(M);
-        if (!ok) break;
-        dPts = bPts.p;
-        dFl = bFl.p;
         std::vector<uint8_t> flags(M, 1);
         const double box[3] = {lead->collisionBox_[0], lead->collisionBox_[1], lead->collisionBox_[2]};
-        ok = hipMemcpy(dPts, pts.data(), M * 24, hipMemcpyHostToDevice) == hipSuccess &&
-             vigo_box_collision_points(lead->dev_, (int64_t)M, (const double*)dPts, box, lead->mapRes_, (uint8_t*)dFl) == VIGO_OK &&
-             hipDeviceSynchronize() == hipSuccess && hipMemcpy(flags.data(), dFl, M, hipMemcpyDeviceToHost) == hipSuccess;
-        if (!ok) break;
+        if (M) {
+            ok = bPts.upload(pts.data(), M * 24) && bFl.alloc(M) &&
+                 vigo_box_collision_points(lead->dev_, (int64_t)M, (const double*)bPts.p, box, lead->mapRes_, (uint8_t*)bFl.p) == VIGO_OK &&
+                 bFl.download(flags.data(), M);
+            if (!ok) break;
+        }
         for (int a = 0; a < T; ++a) {
             const size_t g = act[a];
             polyTrajOctomap* p = ps[grp[g]];
@@ -396,7 +422,12 @@ std::vector<bool> polyTrajOctomap::makePlanBatch(const std::vector<polyTrajOctom
             ++st[g].iters;
             if (!has) { p->findValidTraj_ = true; st[g].active = false; }
             else {
-                for (int sgm : collisionSeg) st[g].corridor[sgm] *= p->fs_;   // adjustCorridorSize, PO.cpp:188-192
+                if (p->mode_) {
+                    p->insertWaypoint(collisionSeg);               // PO.cpp:178-186
+                    p->trajSolver_->updatePath(p->path_);
+                } else {
+                    for (int sgm : collisionSeg) st[g].corridor[sgm] *= p->fs_;   // adjustCorridorSize, PO.cpp:188-192
+                }
                 if (st[g].iters > p->maxIter_ || nowSec() - st[g].t0 >= p->timeout_ * (double)G) st[g].active = false;
             }
             p->lastIterations_ = st[g].iters;

@@ -337,6 +337,58 @@ int main() {
         CHECK(t2.size() == trajs[3].size() && worst < 1e-6 && solo->isValid() == res[3], "batch plan == single makePlan (device QP == host QP)");
     }
 
+    // ---- polyTrajOctomap::makePlanBatch in the ADDING-WAYPOINT mode (PO.cpp:259-386), mixed with corridor-mode planners:
+    //      the paths grow as waypoints are inserted, so each round groups the planners by waypoint count; every
+    //      planner is compared with a twin planned on its own (host QP) ----
+    {
+        auto mk = [&](int i, bool addingWaypoints) {
+            ros::NodeHandle nh;
+            nh.setParam("collision_box", std::vector<double>{0.4, 0.4, 0.2});
+            nh.setParam("map_resolution", 0.2);
+            nh.setParam("sample_delta_time", 0.1);
+            nh.setParam("mode", addingWaypoints ? 1.0 : 0.0);
+            nh.setParam("initial_radius", 0.5);
+            nh.setParam("shrinking_factor", 0.8);
+            nh.setParam("corridor_res", 8.0);
+            nh.setParam("maximum_iteration_num", 12.0);
+            nh.setParam("traj_timeout", 0.5);
+            std::unique_ptr<trajPlanner::polyTrajOctomap> q(new trajPlanner::polyTrajOctomap(nh));
+            q->setMap(map);
+            const double c = 0.75 + 0.05 * i;   // the leg over the pillar (|y| <= 0.8): from grazing it to well clear
+            if (i % 3 == 0) q->updatePath(std::vector<trajPlanner::pose>{{-3, 0.02 * i, 1}, {-1, 0.1, 1}, {1, 0.1, 1}, {3, 0, 1}});   // through it: waypoints are inserted until the limit
+            else if (i % 5 == 4) q->updatePath(std::vector<trajPlanner::pose>{{-3, 0, 1}, {0, c + 0.2, 1}, {3, 0, 1}});
+            else q->updatePath(std::vector<trajPlanner::pose>{{-3, 0, 1}, {-1.1, c, 1}, {1.1, c, 1}, {3, 0, 1}});
+            return q;
+        };
+        std::vector<std::unique_ptr<trajPlanner::polyTrajOctomap>> owners, twins;
+        std::vector<trajPlanner::polyTrajOctomap*> ps;
+        for (int i = 0; i < 32; ++i) {
+            const bool adding = i % 4 != 3;               // 24 adding-waypoint planners, 8 corridor planners
+            owners.push_back(mk(i, adding));
+            twins.push_back(mk(i, adding));
+            ps.push_back(owners.back().get());
+        }
+        std::vector<std::vector<trajPlanner::pose>> trajs;
+        std::vector<bool> res = trajPlanner::polyTrajOctomap::makePlanBatch(ps, trajs);
+        int same = 0, validAdding = 0, grown = 0;
+        double worst = 0;
+        for (size_t i = 0; i < ps.size(); ++i) {
+            std::vector<trajPlanner::pose> t2;
+            twins[i]->makePlan(t2, 0.1);
+            bool eq = twins[i]->isValid() == res[i] && t2.size() == trajs[i].size() && twins[i]->getPath().size() == ps[i]->getPath().size();
+            double w = 0;
+            for (size_t k = 0; eq && k < t2.size(); ++k)
+                w = std::fmax(w, std::fabs(t2[k].x - trajs[i][k].x) + std::fabs(t2[k].y - trajs[i][k].y) + std::fabs(t2[k].z - trajs[i][k].z));
+            eq = eq && w < 1e-9;
+            worst = std::fmax(worst, w);
+            same += eq;
+            if (i % 4 != 3) { validAdding += res[i]; grown += ps[i]->getPath().size() > 4; }
+        }
+        std::printf("INFO poly batch, adding-waypoint mode: %d of 24 valid, %d paths grew; batch vs solo: %d of 32 identical plans, max diff %.3e\n",
+                    validAdding, grown, same, worst);
+        CHECK(same == 32 && grown > 0 && validAdding > 0, "polyTrajOctomap::makePlanBatch, adding-waypoint mode: batch plan == single makePlan");
+    }
+
     // ---- degenerate inputs: the classes answer false / "not found", never crash ----
     {
         const double nan = std::nan("");
