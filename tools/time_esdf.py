@@ -1,0 +1,24 @@
+"""Times vigo_esdf_query at the BASELINE configs[4] size (1 048 576 queries, 256^3 lattice): uniform random and
+brick-sorted query order; prints one JSON line per case.  Run on the GPU box."""
+import json, os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import numpy as np, torch
+from trajectory_planner_amd import synth
+from trajectory_planner_amd.vigo import Vigo
+dev = torch.device("cuda", 0)
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+n = 256
+dist, origin = synth.sphere_esdf(n, 0.1, (0.0, 0.0, 0.0), 5.0)
+v = Vigo(0)
+v.set_esdf(T(dist), origin, 0.1)
+rng = np.random.default_rng(5)
+pts_h = rng.uniform(-12.7, 12.7, size=(1 << 20, 3))
+idx = np.lexsort(tuple(np.floor((pts_h[:, a] + 12.8) / 0.4).astype(int) for a in (2, 1, 0)))
+for name, p in (("uniform random", pts_h), ("brick-sorted", pts_h[idx])):
+    pts = T(p)
+    for _ in range(5): v.esdf_query(pts)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50): d, g = v.esdf_query(pts)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
+    print(json.dumps({"config": "5b: 1M trilinear ESDF queries, " + name, "ms": dt * 1e3, "queries_per_s": (1 << 20) / dt,
+                      "algorithmic_GBps": (1 << 20) * 60 / dt / 1e9, "checksum": float(d.sum().item())}))

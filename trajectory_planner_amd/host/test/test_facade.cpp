@@ -4,6 +4,7 @@
 #include <trajectory_planner/bsplineTraj.h>
 #include <trajectory_planner/polyTrajOctomap.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -233,40 +234,44 @@ int main() {
                     host.msU, host.msP, NP / ((host.msU + host.msP) * 1e-3));
         CHECK(good >= NP * 8 / 10 && clean == good, "1024-planner batch: every success is collision free");
         CHECK(same == NP, "device-resident rebound loop == host-driven loop (control points, success, solver status, bit for bit)");
-        // two batches in flight: two host threads, each planning its own 1024 planners (own handles and staging buffers)
-        {
-            Run A, B2, wA, wB;
-            construct(A);
-            construct(B2);
-            construct(wA);
-            construct(wB);
-            // (a planner service keeps its threads: each worker first plans a warm-up batch, so its thread-local stream
-            // and staging buffers exist, then both start the timed batch together)
+        warm.owners.clear(); warm.ps.clear();                            // (release the node pools of the runs no longer needed)
+        host.owners.clear(); host.ps.clear();
+        // several batches in flight: one host thread per batch, each planning its own 1024 planners (own handles, HIP
+        // streams and staging buffers).  A planner service keeps its threads: each worker first plans a warm-up batch,
+        // so its thread-local stream and buffers exist, then all start their timed batch together.
+        for (int inflight : {2, 4}) {
+            std::vector<Run> timed(inflight);
+            for (int w = 0; w < inflight; ++w) construct(timed[w]);      // (each planner owns a 19 MB A* node pool: ~20 GB per batch)
             std::atomic<int> ready{0};
-            std::chrono::steady_clock::time_point tStart[2], tEnd[2];
-            auto worker = [&](int id, Run& warmRun, Run& timed) {
-                plan(true, warmRun);
+            std::vector<std::chrono::steady_clock::time_point> tStart(inflight), tEnd(inflight);
+            auto worker = [&](int id) {
+                plan(true, timed[id]);                                   // warm-up: the same planners plan the same paths twice
                 ready.fetch_add(1);
-                while (ready.load() < 2) std::this_thread::yield();
+                while (ready.load() < inflight) std::this_thread::yield();
                 tStart[id] = std::chrono::steady_clock::now();
-                plan(true, timed);
+                plan(true, timed[id]);
                 tEnd[id] = std::chrono::steady_clock::now();
             };
-            std::thread ta(worker, 0, std::ref(wA), std::ref(A));
-            std::thread tb(worker, 1, std::ref(wB), std::ref(B2));
-            ta.join();
-            tb.join();
-            const double ms = std::chrono::duration<double, std::milli>(std::max(tEnd[0], tEnd[1]) - std::min(tStart[0], tStart[1])).count();
-            int okBoth = 0, eqBoth = 0;
+            std::vector<std::thread> pool;
+            for (int w = 0; w < inflight; ++w) pool.emplace_back(worker, w);
+            for (auto& t : pool) t.join();
+            const double ms = std::chrono::duration<double, std::milli>(*std::max_element(tEnd.begin(), tEnd.end()) -
+                                                                        *std::min_element(tStart.begin(), tStart.end())).count();
+            int okAll = 0, eqAll = 0;
             for (int i = 0; i < NP; ++i) {
-                okBoth += A.res[i] && B2.res[i];
-                const Eigen::MatrixXd a = A.ps[i]->getControlPoints(), b = dev.ps[i]->getControlPoints(), c = B2.ps[i]->getControlPoints();
-                eqBoth += a.cols() == b.cols() && c.cols() == b.cols() && std::memcmp(a.data(), b.data(), sizeof(double) * 3 * a.cols()) == 0 &&
-                          std::memcmp(c.data(), b.data(), sizeof(double) * 3 * c.cols()) == 0;
+                bool ok = true, eq = true;
+                const Eigen::MatrixXd b = dev.ps[i]->getControlPoints();
+                for (int w = 0; w < inflight; ++w) {
+                    ok = ok && timed[w].res[i];
+                    const Eigen::MatrixXd a = timed[w].ps[i]->getControlPoints();
+                    eq = eq && a.cols() == b.cols() && std::memcmp(a.data(), b.data(), sizeof(double) * 3 * a.cols()) == 0;
+                }
+                okAll += ok;
+                eqAll += eq;
             }
-            std::printf("INFO two batches of 1024 in flight (two host threads, each updatePathBatch + makePlanBatch): %.2f ms, %.0f plans/s, %d planned in both\n",
-                        ms, 2 * NP / (ms * 1e-3), okBoth);
-            CHECK(eqBoth == NP, "concurrent batches give the single-batch control points");
+            std::printf("INFO %d batches of 1024 in flight (one host thread each, updatePathBatch + makePlanBatch): %.2f ms, %.0f plans/s, %d planned in all\n",
+                        inflight, ms, inflight * NP / (ms * 1e-3), okAll);
+            CHECK(eqAll == NP, "concurrent batches give the single-batch control points");
         }
     }
 
