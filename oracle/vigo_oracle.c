@@ -970,6 +970,119 @@ void vgo_ctrl_occupancy(const vgo_grid_t* g, int N, const double* ctrl, uint8_t*
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* the rebound loop's bookkeeping between two A* calls (BT.cpp:403-445, :573-685)         */
+/* ------------------------------------------------------------------------------------ */
+/* findCollisionSeg, BT.cpp:403-445: pairs (first, second) into seg[2 * cap]; returns how many it found (may exceed cap) */
+int vgo_find_collision_seg(const vgo_grid_t* g, int N, const double* ctrl, double not_check_ratio, int32_t* seg, int cap) {
+    int n = 0;
+    int previousHasCollision = 0;
+    int endIdx = (int)((N - 3 - 1) - not_check_ratio * (N - 2 * 3));
+    int pairStartIdx = 3, pairEndIdx = 3;
+    for (int i = 3; i <= endIdx; ++i) {
+        const double* p = ctrl + 3 * i;
+        int hasCollision = vgo_is_inflated_occupied(g, p);
+        if (hasCollision != previousHasCollision) {
+            if (hasCollision) {
+                pairStartIdx = i - 1;
+            } else {
+                pairEndIdx = i;
+                if (n < cap) { seg[2 * n] = pairStartIdx; seg[2 * n + 1] = pairEndIdx; }
+                ++n;
+            }
+        }
+        if (hasCollision && i == endIdx - 1) { /* corner case, BT.cpp:426-430 */
+            pairEndIdx = N - 1;
+            if (n < cap) { seg[2 * n] = pairStartIdx; seg[2 * n + 1] = pairEndIdx; }
+            ++n;
+        }
+        if (i != 3 && !previousHasCollision && !hasCollision) {
+            if (vgo_is_inflated_occupied_line(g, ctrl + 3 * (i - 1), p)) {
+                if (n < cap) { seg[2 * n] = i - 1; seg[2 * n + 1] = i; }
+                ++n;
+            }
+        }
+        previousHasCollision = hasCollision;
+    }
+    return n;
+}
+
+static int index_in_seg(const int32_t* seg, int n, int idx) { /* BT.h:370-377 */
+    for (int k = 0; k < n; ++k)
+        if (idx >= seg[2 * k] && idx <= seg[2 * k + 1]) return 1;
+    return 0;
+}
+
+/* isControlPointRequireNewGuide, BT.h:417-429 (guide pairs of control point i in CSR form) */
+static int require_new_guide(const vigo_params_t* P, int N, const double* ctrl, const int32_t* goff, const double* gpv, int i) {
+    (void)N;
+    const double* c = ctrl + 3 * i;
+    if (goff && gpv) {
+        for (int j = goff[i]; j < goff[i + 1]; ++j) {
+            const double* pv = gpv + 6 * (size_t)j;
+            double dist = sum3((c[0] - pv[0]) * pv[3], (c[1] - pv[1]) * pv[4], (c[2] - pv[2]) * pv[5]);
+            double distErr = P->dthresh - dist;
+            if (distErr > 0) return 0;
+        }
+    }
+    return 1;
+}
+
+/* isReguideRequired, BT.cpp:573-608 with compareCollisionSeg (BT.h:379-403): 1 when a segment asks for A*.  new_seg
+ * receives findCollisionSeg of the current control points (what collisionSeg_ becomes), *n_new its size. */
+int vgo_is_reguide_required(const vigo_params_t* P, const vgo_grid_t* g, int N, const double* ctrl, const int32_t* goff,
+                            const double* gpv, const int32_t* prev_seg, int n_prev, double not_check_ratio, int32_t* new_seg,
+                            int cap, int* n_new) {
+    int n = vgo_find_collision_seg(g, N, ctrl, not_check_ratio, new_seg, cap);
+    *n_new = n;
+    if (n > cap) return 1; /* (more than the state holds: the device hands such a trajectory to the host) */
+    int need = 0;
+    for (int k = 0; k < n; ++k) {
+        int first = new_seg[2 * k], second = new_seg[2 * k + 1];
+        for (int i = first + 1; i <= second - 1; ++i) {
+            if (index_in_seg(prev_seg, n_prev, i)) need |= require_new_guide(P, N, ctrl, goff, gpv, i); /* overlapped point */
+            else need = 1;                                                                              /* new collision point */
+        }
+        if (second - first - 1 == 0) { /* line collision */
+            for (int i = first; i <= second; ++i) {
+                if (index_in_seg(prev_seg, n_prev, i)) need |= require_new_guide(P, N, ctrl, goff, gpv, i);
+                else need = 1;
+            }
+        }
+    }
+    return need;
+}
+
+/* One pass of the loop body of optimizeTrajectory (BT.cpp:619-679) for a trajectory, as far as it needs no A*:
+ * gates, success exit, the failCount >= 4 hand-over, isReguideRequired, weight doubling.  st follows
+ * vigo_rebound_state_t (include/vigo.h); weights = (distance, smoothness, feasibility, dynamic).  Returns the status. */
+int vgo_rebound_decide(const vigo_params_t* P, const vgo_grid_t* g, int N, const double* ctrl, const int32_t* goff,
+                       const double* gpv, int n_obs, const double* obs, double gate_dt, double not_check_ratio,
+                       double* weights, vigo_rebound_state_t* st) {
+    int hasCollision = vgo_traj_collision(g, N, ctrl, P->ts_ctrl, gate_dt, NULL);
+    int hasDynamicCollision = n_obs > 0 ? vgo_traj_dynamic_collision(N, ctrl, P->ts_ctrl, gate_dt, n_obs, obs) : 0;
+    st->gate_static = hasCollision;
+    st->gate_dynamic = hasDynamicCollision;
+    st->rounds += 1;
+    if (!hasCollision && !hasDynamicCollision) { st->status = VIGO_RB_DONE; return st->status; }   /* BT.cpp:628-631 */
+    if (st->fail_count >= 4) { st->status = VIGO_RB_NEEDS_HOST; return st->status; }               /* BT.cpp:640-648: A* */
+    if (hasCollision) {
+        int32_t new_seg[2 * VIGO_MAX_COLLISION_SEGS];
+        int n_new = 0;
+        if (vgo_is_reguide_required(P, g, N, ctrl, goff, gpv, st->seg, st->n_seg, not_check_ratio, new_seg,
+                                    VIGO_MAX_COLLISION_SEGS, &n_new)) {
+            st->status = VIGO_RB_NEEDS_HOST;                                                         /* BT.cpp:659-665: A* */
+            return st->status;
+        }
+        st->n_seg = n_new;                                                                           /* BT.cpp:575 */
+        for (int k = 0; k < 2 * n_new; ++k) st->seg[k] = new_seg[k];
+        weights[0] *= 2.0;                                                                           /* BT.cpp:672 */
+        st->fail_count += 1;
+    }
+    if (hasDynamicCollision) weights[3] *= 2.0;                                                      /* BT.cpp:677-679 */
+    return st->status;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* corridor checker  PO.cpp:547-589, octomap OcTree::search semantics on the dense grid   */
 /* ------------------------------------------------------------------------------------ */
 static int oct_point_collides(const vgo_grid_t* g, float x, float y, float z) {

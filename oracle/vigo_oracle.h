@@ -121,6 +121,17 @@ int vgo_traj_dynamic_collision(int N, const double* ctrl, double ts_ctrl, double
 void vgo_ctrl_occupancy(const vgo_grid_t* g, int N, const double* ctrl, uint8_t* pt,
                         uint8_t* line);
 
+/* the rebound loop's bookkeeping between two A* calls: findCollisionSeg (BT.cpp:403-445), isReguideRequired
+ * (BT.cpp:573-608, BT.h:379-429) and one pass of the loop body of optimizeTrajectory (BT.cpp:619-679) for a trajectory
+ * that needs no A* — the CPU statement of vigo_rebound_rounds' decision kernel */
+int vgo_find_collision_seg(const vgo_grid_t* g, int N, const double* ctrl, double not_check_ratio, int32_t* seg, int cap);
+int vgo_is_reguide_required(const vigo_params_t* P, const vgo_grid_t* g, int N, const double* ctrl, const int32_t* goff,
+                            const double* gpv, const int32_t* prev_seg, int n_prev, double not_check_ratio, int32_t* new_seg,
+                            int cap, int* n_new);
+int vgo_rebound_decide(const vigo_params_t* P, const vgo_grid_t* g, int N, const double* ctrl, const int32_t* goff,
+                       const double* gpv, int n_obs, const double* obs, double gate_dt, double not_check_ratio,
+                       double* weights, vigo_rebound_state_t* st);
+
 /* PO.cpp:547-589 box sweep at one (float) sample position */
 int vgo_box_collision(const vgo_grid_t* g, float px, float py, float pz,
                       const double box[3], double map_res);

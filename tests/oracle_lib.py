@@ -80,6 +80,11 @@ def oracle():
                                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.vgo_esdf_query.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_double, C.POINTER(C.c_float), _dp, _dp, _dp]
         L.vgo_esdf_query_batch.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_double, C.POINTER(C.c_float), C.c_int64, _dp, _dp, _dp]
+        L.vgo_find_collision_seg.restype = C.c_int
+        L.vgo_find_collision_seg.argtypes = [C.POINTER(Grid), C.c_int, _dp, C.c_double, _ip, C.c_int]
+        L.vgo_rebound_decide.restype = C.c_int
+        L.vgo_rebound_decide.argtypes = [C.POINTER(VigoParams), C.POINTER(Grid), C.c_int, _dp, _ip, _dp, C.c_int, _dp, C.c_double,
+                                         C.c_double, _dp, _ip]
         L.vgo_set_pow_mode.argtypes = [C.c_int]
         L.vgo_pow_exact.restype = C.c_double
         L.vgo_pow_exact.argtypes = [C.c_double, C.c_int]

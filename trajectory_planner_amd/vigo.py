@@ -272,6 +272,24 @@ class Vigo:
                                             C.c_void_p(out.evals.data_ptr())), "vigo_optimize")
         return out
 
+    # ---- the rebound loop between two A* calls ---------------------------------------------
+    # vigo_rebound_state_t as int32 columns: status, solve_first, fail_count, gate_static, gate_dynamic, rounds,
+    # lbfgs_status, n_seg, then 2 * VIGO_MAX_COLLISION_SEGS segment indices
+    REBOUND_MAX_SEGS = 48
+    REBOUND_STATE_INTS = 8 + 2 * 48
+    RB_ACTIVE, RB_DONE, RB_NEEDS_HOST = 0, 1, 2
+
+    def rebound_rounds(self, ctrl, guide_off, guide_pv, guide_unk, obs_off, obs, weights, gate_dt, state,
+                       max_rounds=4, not_check_ratio=0.0):
+        """vigo_rebound_rounds: ctrl [B,N,3], weights [B,4] and state [B, REBOUND_STATE_INTS] (int32) are updated in place."""
+        B, N, pc, po, ppv, pu, poo, pob, ns, pw = self._solve_ptrs(ctrl, guide_off, guide_pv, guide_unk, obs_off, obs, weights)
+        if weights is None:
+            raise ValueError("weights [B,4] are required (the loop doubles them per trajectory)")
+        _shape(state, (B, self.REBOUND_STATE_INTS), "state")
+        self._check(self._lib.vigo_rebound_rounds(self._h, B, N, pc, po, ppv, pu, poo, pob, ns, pw, float(gate_dt),
+                                                  float(not_check_ratio), int(max_rounds),
+                                                  _ptr(state, torch.int32, "state", self.device)), "vigo_rebound_rounds")
+
     # ---- spline fit, evaluation and gates -----------------------------------------------
     def bspline_fit(self, points, conds=None, ts=None):
         """bspline::parameterizeToBspline for a batch: points [B,K,3] (+ conds [B,4,3]) -> ctrl [B,K+2,3]"""
