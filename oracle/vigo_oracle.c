@@ -375,7 +375,13 @@ enum {
     ST_ERR_WIDTHTOOSMALL, ST_ERR_INVALIDPARAMETERS, ST_ERR_INCREASEGRADIENT
 };
 
+/* (device emulation) the kernels keep the d of the control points that are not free — the fixed end points and the
+ * lanes beyond N — at zero by giving them zero history; a two-loop coefficient that is not finite (ys = 0: no ys > 0
+ * guard, LB:1300) turns that zero into NaN (0 * inf), and through those lanes' partials every later dot product of
+ * the same two-loop.  g_emu_poisoned is that state, set and cleared by vgo_lbfgs around its two-loop. */
+static int g_emu_poisoned = 0;
 static double dotn(const double* a, const double* b, int n) {
+    if (g_emu_group && g_emu_poisoned) return NAN;
     if (g_emu_group) {
         /* device emulation: control point p owns elements 3(p-3)..3(p-3)+2 */
         double pts[VIGO_MAX_CTRL_POINTS];
@@ -682,6 +688,8 @@ int vgo_lbfgs(int n, double* x, double* fx_out, vgo_eval_fn eval, void* ctx,
 
             for (int i = 0; i < n; ++i) d[i] = -g[i];
             int j = end;
+            g_emu_poisoned = 0;
+#define POISON_IF_NOT_FINITE(c) do { if (g_emu_group && !((c) - (c) == 0.0)) g_emu_poisoned = 1; } while (0)
             for (int i = 0; i < bound; ++i) {
                 j = (j + m - 1) % m;
                 const double* sj = S + (size_t)j * n;
@@ -691,9 +699,11 @@ int vgo_lbfgs(int n, double* x, double* fx_out, vgo_eval_fn eval, void* ctx,
                 double na = -alpha[j];
                 if (FAST) { for (int e = 0; e < n; ++e) d[e] = fma(na, yj[e], d[e]); }
                 else      { for (int e = 0; e < n; ++e) d[e] += na * yj[e]; }
+                POISON_IF_NOT_FINITE(na);
             }
             double sc = ys / yy;
             for (int e = 0; e < n; ++e) d[e] *= sc;
+            POISON_IF_NOT_FINITE(sc);
             for (int i = 0; i < bound; ++i) {
                 const double* sj = S + (size_t)j * n;
                 const double* yj = Y + (size_t)j * n;
@@ -702,8 +712,11 @@ int vgo_lbfgs(int n, double* x, double* fx_out, vgo_eval_fn eval, void* ctx,
                 double co = alpha[j] - beta;
                 if (FAST) { for (int e = 0; e < n; ++e) d[e] = fma(co, sj[e], d[e]); }
                 else      { for (int e = 0; e < n; ++e) d[e] += co * sj[e]; }
+                POISON_IF_NOT_FINITE(co);
                 j = (j + 1) % m;
             }
+#undef POISON_IF_NOT_FINITE
+            g_emu_poisoned = 0;   /* the kernels reset the d of those points after the two-loop */
             step = 1.0;
         }
     }

@@ -802,6 +802,10 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int N = A.N, NI = N - 6;
     const int ROW = TPB * NI;
+    // one more column per slot that holds zeros for good: the history of every control point that is NOT free (the
+    // three fixed points at either end, lanes beyond N).  Their s and y are identically zero, so the two-loop needs
+    // no per-step select to keep their d at zero (two v_cndmask on the dependent chain of each of its 32 steps).
+    const int ROWP = ROW + 1;
     const int m = K.mem_size;
     // REG1 (one control point per lane): the two newest history pairs (ages 0 and 1) stay in
     // registers, LDS holds the older m - 2 — at N = 64, m = 16 that is 38.3 KB instead of 43.8 KB
@@ -809,7 +813,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
     constexpr bool REG1 = (PPL == 1);
     const int ms = REG1 ? (m > 2 ? m - 2 : 0) : m;   // history slots in LDS
     HPair<T>* hist = reinterpret_cast<HPair<T>*>(lds_raw);
-    double* ys_tab = reinterpret_cast<double*>(lds_raw + (((size_t)ms * ROW * sizeof(HPair<T>) + 15) & ~(size_t)15));
+    double* ys_tab = reinterpret_cast<double*>(lds_raw + (((size_t)ms * ROWP * sizeof(HPair<T>) + 15) & ~(size_t)15));
 
     const int lane = threadIdx.x;
     const int grp = lane / GROUP;
@@ -827,15 +831,20 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
     long long tick_ = (long long)__builtin_readcyclecounter();
     double t_eval = 0, t_ls = 0, t_upd = 0, t_two = 0, t_tail = 0, t_pre = 0, t_trial = 0, t_cal = 0;
 #endif
-    // history column of each owned point.  Points that are not free (index < 3 or > N-4) read a
-    // neighbour's column — finite data their zero d/g wipes out — and never write.
+    // history column of each owned point; points that are not free read the zero column and never write
     HPair<T>* hl[PPL];
 #pragma unroll
     for (int q = 0; q < PPL; ++q) {
         const int p = Q.p0 + q;
-        const int pc = (p < 3) ? 3 : ((p > N - 4) ? N - 4 : p);
-        hl[q] = hist + (grp * NI + (pc - 3));
+        hl[q] = Q.interior[q] ? hist + (grp * NI + (p - 3)) : hist + ROW;
     }
+    for (int slot = lane; slot < ms; slot += kWave) {
+        HPair<T> zero;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) zero.s[a] = zero.y[a] = T(0);
+        hist[slot * ROWP + ROW] = zero;
+    }
+    __syncthreads();   // one wave per workgroup: orders the zero column before the first history read
     using YS = YSv<FAST>;
     YS* ys_l = reinterpret_cast<YS*>(ys_tab) + grp;
     double* al_l = ys_tab + 2 * (size_t)m * TPB + grp;
@@ -1029,7 +1038,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
                 HPair<T> hp;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) { hp.s[a] = sv[q][a]; hp.y[a] = yv[q][a]; }
-                hl[q][end * ROW] = hp;
+                hl[q][end * ROWP] = hp;
             }
         }
         double ysyy[2] = {dot_lane<FAST, T, PPL>(yv, sv), dot_lane<FAST, T, PPL>(yv, yv)};
@@ -1079,7 +1088,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
             if (slot < 0) slot += ms;
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
-                const HPair<T> h = hl[q][slot * ROW];
+                const HPair<T> h = hl[q][slot * ROWP];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) { s_[q][a] = h.s[a]; y_[q][a] = h.y[a]; }
             }
@@ -1098,7 +1107,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
             // STEADY: the LDS ring (kMaxMem - 2 slots) is walked with running byte offsets — one
             // add and a wrap per fetch instead of slot arithmetic and two quarter-rate multiplies
             constexpr int kRing = kMaxMem - 2;
-            const int stepB = ROW * (int)sizeof(HPair<T>), stepY = TPB * (int)sizeof(YS);
+            const int stepB = ROWP * (int)sizeof(HPair<T>), stepY = TPB * (int)sizeof(YS);
             // (the slot index is the same in every live lane — all trajectories of a wave are in the
             // same iteration — and is taken through an SGPR so the ring walk is scalar work; the caller
             // checks the uniformity)
@@ -1137,11 +1146,12 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
                     al = over_ys<MARK>(al, Pys[w], amin, amax);
                     if (STEADY) al_reg[STEADY ? age : 0] = al;
                     else al_l[age * TPB] = al;         // alpha_j parks in LDS at a static offset
+                    {
+                        const T na = (T)(-al);     // (points that are not free hold y = 0: no select, see ROWP)
 #pragma unroll
-                    for (int q = 0; q < PPL; ++q) {
-                        const T na = Q.interior[q] ? (T)(-al) : T(0);
+                        for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                        for (int a = 0; a < 3; ++a) d[q][a] = FAST ? fmaT(na, Py[w][q][a], d[q][a]) : d[q][a] + na * Py[w][q][a];
+                            for (int a = 0; a < 3; ++a) d[q][a] = FAST ? fmaT(na, Py[w][q][a], d[q][a]) : d[q][a] + na * Py[w][q][a];
                     }
                     if (age + kWin < kMaxMem && age + kWin < bnd) {
                         if (STEADY && age + kWin >= 2) { ring_fetch(Ps[w], Py[w], Pys[w]); ring_older(); }
@@ -1173,11 +1183,12 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
                     double beta = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(Py[w], d));
                     beta = over_ys<MARK>(beta, Pys[w], amin, amax);
                     const double cod = (STEADY ? al_reg[STEADY ? age : 0] : al_l[age * TPB]) - beta;
+                    {
+                        const T co = (T)cod;
 #pragma unroll
-                    for (int q = 0; q < PPL; ++q) {
-                        const T co = Q.interior[q] ? (T)cod : T(0);
+                        for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                        for (int a = 0; a < 3; ++a) d[q][a] = FAST ? fmaT(co, Ps[w][q][a], d[q][a]) : d[q][a] + co * Ps[w][q][a];
+                            for (int a = 0; a < 3; ++a) d[q][a] = FAST ? fmaT(co, Ps[w][q][a], d[q][a]) : d[q][a] + co * Ps[w][q][a];
                     }
                     if (age - kWin >= 0) {
                         if (STEADY && age - kWin >= 2) { ring_fetch(Ps[w], Py[w], Pys[w]); ring_newer(); }
@@ -1208,6 +1219,14 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
         } else {
             two_loop(std::false_type{});
         }
+        // A coefficient that is not finite (ys = 0: the reference has no ys > 0 guard, LB:1300) turns the zero d of the
+        // points that are not free into NaN (0 * inf) — and through their lanes' partials every later dot product of
+        // that two-loop, which oracle/vigo_oracle.c's emulation mirrors.  Those points never move: their d is reset
+        // here, once per iteration instead of in every step.
+#pragma unroll
+        for (int q = 0; q < PPL; ++q)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) d[q][a] = Q.interior[q] ? d[q][a] : T(0);
         VIGO_TICK(t_two);
         if (REG1) {
             // the age-1 pair turns age 2 for the next two-loop: it leaves the registers for the LDS
@@ -1219,7 +1238,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
                         HPair<T> hp;
 #pragma unroll
                         for (int a = 0; a < 3; ++a) { hp.s[a] = s1[q][a]; hp.y[a] = y1[q][a]; }
-                        hl[q][end * ROW] = hp;
+                        hl[q][end * ROWP] = hp;
                     }
                 }
                 ys_l[end * TPB] = ys1;
@@ -1266,7 +1285,7 @@ template <typename T, int GROUP>
 size_t optimize_lds_bytes(int N, int m, int ppl, bool with_obstacles) {
     const int TPB = kWave / GROUP;
     const int ms = ppl == 1 ? (m > 2 ? m - 2 : 0) : m;   // REG1: ages 0 and 1 live in registers
-    size_t h = (size_t)ms * TPB * (N - 6) * sizeof(HPair<T>);
+    size_t h = (size_t)ms * ((size_t)TPB * (N - 6) + 1) * sizeof(HPair<T>);   // + the zero column of every slot
     h = (h + 15) & ~(size_t)15;
     h += 3 * (size_t)m * TPB * sizeof(double);   // {ys, 1/ys} per slot + the alphas
     if (with_obstacles) h += (size_t)TPB * kObsTabDoubles<GROUP> * sizeof(double);
