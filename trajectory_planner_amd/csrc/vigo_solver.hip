@@ -26,6 +26,10 @@
 
 #include "vigo_internal.hpp"
 
+#ifndef VIGO_DOUBLE_ADD
+#define VIGO_DOUBLE_ADD 1
+#endif
+
 namespace vigo {
 namespace {
 
@@ -142,6 +146,21 @@ __device__ __forceinline__ double xor32_sum(double v) {
     auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
     return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
 }
+// The xor-16 level needs the value twice (v_permlane16_swap exchanges rows between TWO registers and clobbers
+// both).  Instead of copying the result of the row_mirror level (two v_mov_b32), that level's add is issued twice:
+// one VALU slot instead of two.  The second add is an asm statement so that it is not merged with the first (the
+// compiler still sees its register definition and keeps the VALU-write -> permlane-read wait states after it).
+__device__ __forceinline__ double add_f64_again(double a, double b) {
+    double r;
+    asm volatile("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double xor16_sum2(double a, double b) {   // a == b bitwise, in two registers
+    const int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+}
 template <int GROUP, int K>
 __device__ __forceinline__ void group_sum(double (&v)[K]) {
     static_assert(GROUP == 16 || GROUP == 32 || GROUP == 64, "group is a DPP row, half a wave or a wave");
@@ -151,11 +170,21 @@ __device__ __forceinline__ void group_sum(double (&v)[K]) {
     for (int q = 0; q < K; ++q) v[q] += dpp_f64<0x4E>(v[q]);   // quad_perm:[2,3,0,1]
 #pragma unroll
     for (int q = 0; q < K; ++q) v[q] += dpp_f64<0x141>(v[q]);  // row_half_mirror
+    if (GROUP >= 32 && VIGO_DOUBLE_ADD) {
 #pragma unroll
-    for (int q = 0; q < K; ++q) v[q] += dpp_f64<0x140>(v[q]);  // row_mirror
-    if (GROUP >= 32) {
+        for (int q = 0; q < K; ++q) {
+            const double t = dpp_f64<0x140>(v[q]);             // row_mirror
+            const double a = v[q] + t;
+            const double b = add_f64_again(v[q], t);
+            v[q] = xor16_sum2(a, b);
+        }
+    } else {
 #pragma unroll
-        for (int q = 0; q < K; ++q) v[q] = xor16_sum(v[q]);
+        for (int q = 0; q < K; ++q) v[q] += dpp_f64<0x140>(v[q]);  // row_mirror
+        if (GROUP >= 32) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) v[q] = xor16_sum(v[q]);
+        }
     }
     if (GROUP == 64) {
 #pragma unroll
@@ -765,6 +794,9 @@ __device__ __forceinline__ int trial_interval(double& xt, double& xf, double& xd
 // iteration boundary and run the (dominant) two-loop recursion together.
 #ifndef VIGO_TWOLOOP_WIN
 #define VIGO_TWOLOOP_WIN 2
+#endif
+#ifndef VIGO_DOUBLE_ADD
+#define VIGO_DOUBLE_ADD 1
 #endif
 #ifndef VIGO_TWOLOOP_STEADY
 #define VIGO_TWOLOOP_STEADY 1
