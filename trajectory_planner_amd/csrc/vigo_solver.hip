@@ -38,9 +38,10 @@ constexpr int kMaxMem = VIGO_MAX_MEM_SIZE;
 // Dynamic-obstacle table of the solve kernel: per trajectory, {predicted x, predicted y, threshold}
 // of up to kObsTabEntries (obstacle, predicted step) pairs plus the obstacles' sizes, staged in LDS
 // once per solve (they do not depend on the control points).  Sized so that the N = 32 and N = 64
-// shapes keep four waves per CU (<= 40 KiB per wave).
+// shapes keep four waves per CU (<= 40 KiB per wave, history slots with their zero column included):
+// 8 obstacles x 11 predicted steps for two trajectories per wave, 3 x 11 for one.
 constexpr int kObsTabObs = 16;
-template <int GROUP> constexpr int kObsTabEntries = GROUP == 32 ? 96 : 44;
+template <int GROUP> constexpr int kObsTabEntries = GROUP == 32 ? 88 : 33;
 template <int GROUP> constexpr int kObsTabDoubles = 3 * kObsTabEntries<GROUP> + kObsTabObs;
 
 // reference status codes, LB:20-80
@@ -838,6 +839,11 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
     // three fixed points at either end, lanes beyond N).  Their s and y are identically zero, so the two-loop needs
     // no per-step select to keep their d at zero (two v_cndmask on the dependent chain of each of its 32 steps).
     const int ROWP = ROW + 1;
+    using YS = YSv<FAST>;
+    // A history slot = its ROWP records followed by the slot's {ys, 1/ys} per trajectory, so the steady-state ring
+    // walks ONE byte offset for both (slot stride in bytes, a multiple of 16 for the ds_read_b128s)
+    constexpr int kYsSlotBytes = (TPB * (int)sizeof(YS) + 15) & ~15;
+    const int slotB = ROWP * (int)sizeof(HPair<T>) + kYsSlotBytes;
     const int m = K.mem_size;
     // REG1 (one control point per lane): the two newest history pairs (ages 0 and 1) stay in
     // registers, LDS holds the older m - 2 — at N = 64, m = 16 that is 38.3 KB instead of 43.8 KB
@@ -845,7 +851,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
     constexpr bool REG1 = (PPL == 1);
     const int ms = REG1 ? (m > 2 ? m - 2 : 0) : m;   // history slots in LDS
     HPair<T>* hist = reinterpret_cast<HPair<T>*>(lds_raw);
-    double* ys_tab = reinterpret_cast<double*>(lds_raw + (((size_t)ms * ROWP * sizeof(HPair<T>) + 15) & ~(size_t)15));
+    double* ys_tab = reinterpret_cast<double*>(lds_raw + (size_t)ms * slotB);   // alphas, obstacle table
 
     const int lane = threadIdx.x;
     const int grp = lane / GROUP;
@@ -874,17 +880,20 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
         HPair<T> zero;
 #pragma unroll
         for (int a = 0; a < 3; ++a) zero.s[a] = zero.y[a] = T(0);
-        hist[slot * ROWP + ROW] = zero;
+        *reinterpret_cast<HPair<T>*>(lds_raw + (size_t)slot * slotB + (size_t)ROW * sizeof(HPair<T>)) = zero;
     }
     __syncthreads();   // one wave per workgroup: orders the zero column before the first history read
-    using YS = YSv<FAST>;
-    YS* ys_l = reinterpret_cast<YS*>(ys_tab) + grp;
-    double* al_l = ys_tab + 2 * (size_t)m * TPB + grp;
+    YS* ys_l = reinterpret_cast<YS*>(lds_raw + (size_t)ROWP * sizeof(HPair<T>)) + grp;   // slot 0; slot k at + k * slotB bytes
+    double* al_l = ys_tab + grp;
+    auto hist_at = [&](int q, int slot) -> HPair<T>& {
+        return *reinterpret_cast<HPair<T>*>(reinterpret_cast<char*>(hl[q]) + (size_t)slot * slotB);
+    };
+    auto ys_at = [&](int slot) -> YS& { return *reinterpret_cast<YS*>(reinterpret_cast<char*>(ys_l) + (size_t)slot * slotB); };
     if (A.obs) {
         // stage this trajectory's obstacles once: the predicted positions and thresholds of
         // BT.cpp:1011-1020 by the expressions of obstacle_term(), sizes in T arithmetic
         constexpr int kEnt = kObsTabEntries<GROUP>;
-        double* tab = ys_tab + 3 * (size_t)m * TPB + (size_t)grp * kObsTabDoubles<GROUP>;
+        double* tab = ys_tab + (size_t)m * TPB + (size_t)grp * kObsTabDoubles<GROUP>;
         const int cnt = Q.o_end - Q.o_begin;
         const int steps = K.pred_num / 2 + 1;
         int fit = kEnt / steps;
@@ -1070,7 +1079,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
                 HPair<T> hp;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) { hp.s[a] = sv[q][a]; hp.y[a] = yv[q][a]; }
-                hl[q][end * ROWP] = hp;
+                hist_at(q, end) = hp;
             }
         }
         double ysyy[2] = {dot_lane<FAST, T, PPL>(yv, sv), dot_lane<FAST, T, PPL>(yv, yv)};
@@ -1078,7 +1087,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
         const double ys = ysyy[0], yy = ysyy[1];
         // the two-loop divides by ys of each pair (LB:1300, :1312); FAST keeps its reciprocal instead
         const YS ys_div = make_ys(ys, static_cast<YS*>(nullptr));
-        if (!REG1) ys_l[end * TPB] = ys_div;
+        if (!REG1) ys_at(end) = ys_div;
         const bool have1 = REG1 && k >= 2;   // s1/y1 hold the previous iteration's pair (age 1 now)
 
         // two-loop recursion, LB:1286-1316, fully unrolled over the pair's age with a register
@@ -1120,11 +1129,11 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
             if (slot < 0) slot += ms;
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
-                const HPair<T> h = hl[q][slot * ROWP];
+                const HPair<T> h = hist_at(q, slot);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) { s_[q][a] = h.s[a]; y_[q][a] = h.y[a]; }
             }
-            ys_ = ys_l[slot * TPB];
+            ys_ = ys_at(slot);
         };
         // STEADY: the history is full (bound == kMaxMem, every iteration after the 16th): `age <
         // bound` is true at compile time, so the 32 steps are straight-line code — no exec-mask
@@ -1139,12 +1148,12 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
             // STEADY: the LDS ring (kMaxMem - 2 slots) is walked with running byte offsets — one
             // add and a wrap per fetch instead of slot arithmetic and two quarter-rate multiplies
             constexpr int kRing = kMaxMem - 2;
-            const int stepB = ROWP * (int)sizeof(HPair<T>), stepY = TPB * (int)sizeof(YS);
+            const int stepB = slotB;
             // (the slot index is the same in every live lane — all trajectories of a wave are in the
             // same iteration — and is taken through an SGPR so the ring walk is scalar work; the caller
             // checks the uniformity)
             const int lastU = STEADY ? __builtin_amdgcn_readfirstlane(last) : 0;
-            int curB = lastU * stepB, curY = lastU * stepY;   // slot of the age-2 pair
+            int curB = lastU * stepB;   // slot of the age-2 pair
             auto ring_fetch = [&](T (&s_)[PPL][3], T (&y_)[PPL][3], YS& ys_) {
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) {
@@ -1152,15 +1161,15 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
                     for (int a = 0; a < 3; ++a) { s_[q][a] = h.s[a]; y_[q][a] = h.y[a]; }
                 }
-                ys_ = *reinterpret_cast<const YS*>(reinterpret_cast<const char*>(ys_l) + curY);
+                ys_ = *reinterpret_cast<const YS*>(reinterpret_cast<const char*>(ys_l) + curB);
             };
             auto ring_older = [&]() {   // towards higher ages: one slot down, wrapping
-                curB -= stepB; curY -= stepY;
-                if (curB < 0) { curB += kRing * stepB; curY += kRing * stepY; }
+                curB -= stepB;
+                if (curB < 0) curB += kRing * stepB;
             };
             auto ring_newer = [&]() {
-                curB += stepB; curY += stepY;
-                if (curB >= kRing * stepB) { curB -= kRing * stepB; curY -= kRing * stepY; }
+                curB += stepB;
+                if (curB >= kRing * stepB) curB -= kRing * stepB;
             };
 #pragma unroll
             for (int q = 0; q < PPL; ++q)
@@ -1270,10 +1279,10 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
                         HPair<T> hp;
 #pragma unroll
                         for (int a = 0; a < 3; ++a) { hp.s[a] = s1[q][a]; hp.y[a] = y1[q][a]; }
-                        hl[q][end * ROWP] = hp;
+                        hist_at(q, end) = hp;
                     }
                 }
-                ys_l[end * TPB] = ys1;
+                ys_at(end) = ys1;
                 last = end;
                 end = (end + 1 == ms) ? 0 : end + 1;
             }
@@ -1313,13 +1322,14 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
     }
 }
 
-template <typename T, int GROUP>
+template <typename T, int GROUP, bool FAST>
 size_t optimize_lds_bytes(int N, int m, int ppl, bool with_obstacles) {
     const int TPB = kWave / GROUP;
     const int ms = ppl == 1 ? (m > 2 ? m - 2 : 0) : m;   // REG1: ages 0 and 1 live in registers
-    size_t h = (size_t)ms * ((size_t)TPB * (N - 6) + 1) * sizeof(HPair<T>);   // + the zero column of every slot
-    h = (h + 15) & ~(size_t)15;
-    h += 3 * (size_t)m * TPB * sizeof(double);   // {ys, 1/ys} per slot + the alphas
+    // per slot: one record per free control point + the zero column, then {ys, 1/ys} per trajectory (see k_optimize)
+    const size_t slot = ((size_t)TPB * (N - 6) + 1) * sizeof(HPair<T>) + (((size_t)TPB * sizeof(YSv<FAST>) + 15) & ~(size_t)15);
+    size_t h = (size_t)ms * slot;
+    h += (size_t)m * TPB * sizeof(double);        // the alphas of the general two-loop
     if (with_obstacles) h += (size_t)TPB * kObsTabDoubles<GROUP> * sizeof(double);
     return h;
 }
@@ -1404,7 +1414,7 @@ static int raise_dynamic_lds(LaunchState& L, int slot, KernelT kernel) {
 template <typename T, int GROUP, int PPL, bool FAST>
 static int launch_optimize_t(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, LaunchState& L) {
     const int tpb = kWave / GROUP;
-    const size_t lds = optimize_lds_bytes<T, GROUP>(a.N, k.mem_size, PPL, a.obs != nullptr);
+    const size_t lds = optimize_lds_bytes<T, GROUP, FAST>(a.N, k.mem_size, PPL, a.obs != nullptr);
     if (lds > kLdsPerWorkgroup) return (int)hipErrorInvalidValue;  // refused earlier by vigo_optimize
     dim3 grid((a.B + tpb - 1) / tpb), block(kWave);
     // slot = arithmetic (fp32 / fp64 / fp64 fast) x shape (GROUP, PPL) x waves per SIMD
@@ -1449,8 +1459,9 @@ int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, const 
 size_t optimize_lds_requirement(int N, int mem_size, int precision) {
     const bool g32 = N <= 32;
     const int ppl = N <= 64 ? 1 : (N <= 128 ? 2 : 4);
-    if (precision == VIGO_PREC_F32) return g32 ? optimize_lds_bytes<float, 32>(N, mem_size, ppl, true) : optimize_lds_bytes<float, 64>(N, mem_size, ppl, true);
-    return g32 ? optimize_lds_bytes<double, 32>(N, mem_size, ppl, true) : optimize_lds_bytes<double, 64>(N, mem_size, ppl, true);
+    if (precision == VIGO_PREC_F32) return g32 ? optimize_lds_bytes<float, 32, false>(N, mem_size, ppl, true) : optimize_lds_bytes<float, 64, false>(N, mem_size, ppl, true);
+    if (precision == VIGO_PREC_F64_FAST) return g32 ? optimize_lds_bytes<double, 32, true>(N, mem_size, ppl, true) : optimize_lds_bytes<double, 64, true>(N, mem_size, ppl, true);
+    return g32 ? optimize_lds_bytes<double, 32, false>(N, mem_size, ppl, true) : optimize_lds_bytes<double, 64, false>(N, mem_size, ppl, true);
 }
 
 }  // namespace vigo
