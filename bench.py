@@ -164,8 +164,13 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
 
+    # Rehearsal (gloo, every rank on cuda:0) takes the SAME tensor placement as the real runs — device tensors handed
+    # to the collectives — so the 2-rank test on a one-GPU box exercises the code path RCCL will see; host staging is
+    # only the fallback for a gloo build without device-tensor support (VIGO_REHEARSE_HOST_STAGING=1).
+    host_staging = args.rehearse_on_one_gpu and os.environ.get("VIGO_REHEARSE_HOST_STAGING") == "1"
+
     def bcast(t):
-        if args.rehearse_on_one_gpu:      # gloo: stage through the host
+        if host_staging:
             h = t.cpu()
             dist.broadcast(h, src=0)
             t.copy_(h)
@@ -173,7 +178,7 @@ def main():
             dist.broadcast(t, src=0)
 
     def max_over_ranks(x):
-        te = torch.tensor([x], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
+        te = torch.tensor([x], dtype=torch.float64, device="cpu" if host_staging else dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         return float(te.item())
 
@@ -250,7 +255,9 @@ def main():
         # every rank answers the same seeded point queries from the snapshot it adopted; the answers must agree
         qp = T(np.random.default_rng(99).uniform(world.origin.min() - 0.5, -world.origin.min() + 0.5, size=(4096, 3)))
         sig = torch.stack([v.query_points(qp, w).to(torch.float64) @ torch.arange(1, 4097, dtype=torch.float64, device=dev)
-                           for w in (0, 1)]).cpu()
+                           for w in (0, 1)])
+        if host_staging:
+            sig = sig.cpu()
         lo, hi = sig.clone(), sig.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
