@@ -1081,7 +1081,8 @@ int vgo_rebound_decide(const vigo_params_t* P, const vgo_grid_t* g, int N, const
     if (hasCollision) {
         int32_t new_seg[2 * VIGO_MAX_COLLISION_SEGS];
         int n_new = 0;
-        if (vgo_is_reguide_required(P, g, N, ctrl, goff, gpv, st->seg, st->n_seg, not_check_ratio, new_seg,
+        int n_prev = st->n_seg < 0 ? 0 : (st->n_seg > VIGO_MAX_COLLISION_SEGS ? VIGO_MAX_COLLISION_SEGS : st->n_seg);
+        if (vgo_is_reguide_required(P, g, N, ctrl, goff, gpv, st->seg, n_prev, not_check_ratio, new_seg,
                                     VIGO_MAX_COLLISION_SEGS, &n_new)) {
             st->status = VIGO_RB_NEEDS_HOST;                                                         /* BT.cpp:659-665: A* */
             return st->status;

@@ -48,11 +48,52 @@ def test_null_handle_is_refused_everywhere(raw):
         lambda: L.vigo_ctrl_occupancy(NULL, 1, 8, dptr(d), dptr(o), dptr(o)),
         lambda: L.vigo_box_collision_points(NULL, 1, dptr(d), three, 0.1, dptr(o)),
         lambda: L.vigo_esdf_query(NULL, 1, dptr(d), dptr(d), dptr(d)),
+        lambda: L.vigo_poly_sample(NULL, 1, 7, dptr(d), dptr(d), dptr(d), 4, dptr(d), NULL),
+        lambda: L.vigo_rebound_rounds(NULL, 1, 8, dptr(d), NULL, NULL, NULL, NULL, NULL, 0, dptr(d), 0.05, 0.0, 1, dptr(d)),
         lambda: L.vigo_destroy(NULL),
     ]
     for i, f in enumerate(calls):
         assert f() < 0, i
     L.vigo_last_error(NULL)                            # a static message or NULL, not a crash
+
+
+def test_new_entry_points_refuse_bad_arguments(raw):
+    """vigo_poly_sample / vigo_rebound_rounds: negative counts, NULL arrays, out-of-range rounds and ratios are
+    refused on the host (negative status, nothing launched); the host utilities answer NaN outside their domain"""
+    import math
+    L, h = raw
+    d = torch.zeros(4096, dtype=torch.float64, device="cuda")
+    i32 = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    assert L.vigo_poly_sample(h, -1, 7, dptr(d), dptr(i32), dptr(d), 4, dptr(d), NULL) < 0
+    assert L.vigo_poly_sample(h, 2, 16, dptr(d), dptr(i32), dptr(d), 4, dptr(d), NULL) < 0         # degree > 15
+    assert L.vigo_poly_sample(h, 2, 7, NULL, dptr(i32), dptr(d), 4, dptr(d), NULL) < 0
+    assert L.vigo_poly_sample(h, 2, 7, dptr(d), dptr(i32), dptr(d), 4, NULL, NULL) < 0              # no output at all
+    assert L.vigo_poly_sample(h, 0, 7, NULL, NULL, NULL, 0, NULL, NULL) == 0                        # empty is fine
+    three = (C.c_double * 3)(0, 0, 0)
+    vox = torch.zeros(8 * 8 * 40, dtype=torch.uint8, device="cuda")
+    assert L.vigo_set_grid(h, 8, 8, 40, three, 0.1, dptr(vox)) == 0
+    args = lambda **kw: [kw.get("B", 2), kw.get("N", 32), dptr(d), NULL, NULL, NULL, NULL, NULL, 0, kw.get("w", dptr(d)),
+                         kw.get("dt", 0.05), kw.get("ncr", 0.0), kw.get("rounds", 2), kw.get("state", dptr(i32))]
+    assert L.vigo_rebound_rounds(h, *args(w=NULL)) < 0
+    assert L.vigo_rebound_rounds(h, *args(state=NULL)) < 0
+    assert L.vigo_rebound_rounds(h, *args(rounds=-1)) < 0 and L.vigo_rebound_rounds(h, *args(rounds=65)) < 0
+    assert L.vigo_rebound_rounds(h, *args(ncr=1.0)) < 0 and L.vigo_rebound_rounds(h, *args(ncr=float("nan"))) < 0
+    assert L.vigo_rebound_rounds(h, *args(dt=0.0)) < 0 and L.vigo_rebound_rounds(h, *args(dt=float("nan"))) < 0
+    assert L.vigo_rebound_rounds(h, *args(N=6)) < 0 and L.vigo_rebound_rounds(h, *args(B=-1)) < 0
+    assert L.vigo_rebound_rounds(h, *args(B=0)) == 0
+    # state entries with a status the call does not know, a negative failCount or a segment count beyond the array:
+    # treated as "not active" / handed to the host, never indexed out of range
+    st = torch.zeros(4, 104, dtype=torch.int32, device="cuda")
+    st[0, 0] = 7
+    st[1, 7] = 1000
+    st[2, 2] = -5
+    st[:, 1] = 1
+    ctrl = torch.randn(4, 32, 3, dtype=torch.float64, device="cuda")
+    w = torch.ones(4, 4, dtype=torch.float64, device="cuda")
+    assert L.vigo_rebound_rounds(h, 4, 32, dptr(ctrl), NULL, NULL, NULL, NULL, NULL, 0, dptr(w), 0.05, 0.0, 3, dptr(st)) == 0
+    torch.cuda.synchronize()
+    assert int(st[0, 0]) == 7 and bool(torch.isfinite(w).all())
+    assert math.isnan(L.vigo_exact_pow(2.0, -1)) and math.isnan(L.vigo_exact_pow(2.0, 16)) and L.vigo_exact_pow(2.0, 10) == 1024.0
 
 
 def test_bad_arguments_return_codes_and_keep_the_handle_usable(raw):

@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(64) k_rebound_decide(GridView g, ReboundArgs A
             // isReguideRequired, BT.cpp:573-608: a control point inside a new segment that no previous segment covers,
             // or a covered one that fails isControlPointRequireNewGuide (BT.h:417-429), asks for A*
             if (!need_host) {
-                const int n_prev = st.n_seg;
+                const int n_prev = min(max(st.n_seg, 0), (int)VIGO_MAX_COLLISION_SEGS);   // (device data: never index beyond the array)
                 auto in_prev = [&](int i) {
                     for (int k = 0; k < n_prev; ++k)
                         if (i >= st.seg[2 * k] && i <= st.seg[2 * k + 1]) return true;
