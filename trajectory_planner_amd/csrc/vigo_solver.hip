@@ -156,10 +156,19 @@ __device__ __forceinline__ double add_f64_again(double a, double b) {
     asm volatile("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ double xor16_sum2(double a, double b) {   // a == b bitwise, in two registers
+// (a == b bitwise, in two registers; the two halves of the result are returned so that a 64-lane group can issue the
+// final add twice as well, for its xor-32 level)
+__device__ __forceinline__ void xor16_parts(double a, double b, double& p0, double& p1) {
     const int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
     auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
     auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    p0 = __hiloint2double(h[0], l[0]);
+    p1 = __hiloint2double(h[1], l[1]);
+}
+__device__ __forceinline__ double xor32_sum2(double a, double b) {
+    const int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
     return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
 }
 template <int GROUP, int K>
@@ -177,15 +186,18 @@ __device__ __forceinline__ void group_sum(double (&v)[K]) {
             const double t = dpp_f64<0x140>(v[q]);             // row_mirror
             const double a = v[q] + t;
             const double b = add_f64_again(v[q], t);
-            v[q] = xor16_sum2(a, b);
+            double p0, p1;
+            xor16_parts(a, b, p0, p1);
+            if (GROUP == 64) v[q] = xor32_sum2(p0 + p1, add_f64_again(p0, p1));
+            else v[q] = p0 + p1;
         }
-    } else {
+        return;
+    }
 #pragma unroll
-        for (int q = 0; q < K; ++q) v[q] += dpp_f64<0x140>(v[q]);  // row_mirror
-        if (GROUP >= 32) {
+    for (int q = 0; q < K; ++q) v[q] += dpp_f64<0x140>(v[q]);  // row_mirror
+    if (GROUP >= 32) {
 #pragma unroll
-            for (int q = 0; q < K; ++q) v[q] = xor16_sum(v[q]);
-        }
+        for (int q = 0; q < K; ++q) v[q] = xor16_sum(v[q]);
     }
     if (GROUP == 64) {
 #pragma unroll
