@@ -275,6 +275,50 @@ int main() {
         }
     }
 
+    // ---- a batch of planners with DIFFERENT yaml values and maps: each is solved with its own parameters (the batch is
+    //      split into groups the device state fits), i.e. exactly as if it had been planned alone ----
+    {
+        auto otherMap = makeMap();
+        auto mk = [&](int variant, const std::shared_ptr<mapManager::occMap>& m) {
+            ros::NodeHandle nh = makeParams();
+            if (variant == 1) nh.setParam("bspline_traj/distance_threshold", 0.7);
+            if (variant == 2) { nh.setParam("bspline_traj/weight_smoothness", 2.5); nh.setParam("bspline_traj/timestep", 0.05); }
+            std::unique_ptr<bsplineTraj> q(new bsplineTraj(nh));
+            q->setMap(m);
+            q->updateMaxVel(variant == 3 ? 1.5 : 2.0);
+            q->updateMaxAcc(3.0);
+            return q;
+        };
+        std::vector<std::unique_ptr<bsplineTraj>> mixed, alone;
+        std::vector<bsplineTraj*> ps;
+        std::vector<nav_msgs::Path> paths;
+        for (int i = 0; i < 20; ++i) {
+            const int variant = i % 5;                                   // 4 = the default parameters on a second map object
+            mixed.push_back(mk(variant, variant == 4 ? otherMap : map));
+            alone.push_back(mk(variant, variant == 4 ? otherMap : map));
+            ps.push_back(mixed.back().get());
+            paths.push_back(straight(-3.0, -0.5 + 0.06 * i, 3.0, 0.3 - 0.04 * i, 1.0, 0.25));
+        }
+        // (both sides take the host's single-path fit: the batched fit differs from it in the 10th digit, which 50 L-BFGS
+        // iterations amplify to 1e-3 — with the same control points in, the plans must come out identical)
+        std::vector<bool> up(ps.size());
+        for (size_t i = 0; i < ps.size(); ++i) up[i] = ps[i]->updatePath(paths[i], cond);
+        std::vector<bool> res = bsplineTraj::makePlanBatch(ps);
+        int same = 0;
+        for (size_t i = 0; i < ps.size(); ++i) {
+            const bool u = alone[i]->updatePath(paths[i], cond);
+            const bool r = u && alone[i]->makePlan();
+            const Eigen::MatrixXd a = ps[i]->getControlPoints(), b = alone[i]->getControlPoints();
+            double worst = 0;
+            for (int c = 0; c < a.cols() && c < b.cols(); ++c) for (int k = 0; k < 3; ++k) worst = std::fmax(worst, std::fabs(a(k, c) - b(k, c)));
+            const bool ok = (u == (bool)up[i]) && (r == (bool)res[i]) && a.cols() == b.cols() && worst == 0.0;
+            if (!ok) std::printf("INFO mixed batch planner %zu (variant %zu): update %d/%d plan %d/%d cols %d/%d worst %.3e\n", i, i % 5, (int)up[i], (int)u,
+                                 (int)res[i], (int)r, (int)a.cols(), (int)b.cols(), worst);
+            same += ok;
+        }
+        CHECK(same == (int)ps.size(), "a batch of planners with different parameters and maps == each planned alone");
+    }
+
     // ---- polyTrajOctomap checker ----
     {
         ros::NodeHandle nh;
