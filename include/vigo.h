@@ -387,7 +387,10 @@ double vigo_exact_pow(double t, int d);
 double vigo_exact_pow_dd(double t, int d, int* ambiguous);
 double vigo_exact_pow_integer(double t, int d);
 
-/* ---- ESDF trilinear query (config 5; no reference counterpart) ------- */
+/* ---- ESDF trilinear query (config 5; no reference counterpart) -------
+ * vigo_set_esdf copies the row-major float lattice dist_dev[nx][ny][nz] (device memory) into the handle's own layout
+ * (overlapping 4x4x4 bricks): 2.37x the lattice's bytes of device memory, stream-ordered, the caller's
+ * buffer is not referenced afterwards.  nx, ny, nz >= 2. */
 
 int vigo_set_esdf(vigo_handle_t h, int nx, int ny, int nz, const double origin[3],
                   double res, const float* dist_dev);

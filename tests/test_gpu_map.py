@@ -204,6 +204,26 @@ def test_esdf_query_matches_oracle_and_sphere(vigo_handle):
     assert np.max(np.abs(d[far] - (np.linalg.norm(r[far], axis=1) - 1.0))) < 1e-2
 
 
+@pytest.mark.parametrize("shape", [(2, 2, 2), (2, 3, 4), (5, 6, 7), (17, 9, 31), (64, 65, 66), (33, 2, 100)])
+def test_esdf_query_ragged_lattices(vigo_handle, shape):
+    """Every residue of the lattice size modulo the brick step (overlapping bricks hold 3 cells per axis), the minimum
+    size, non-cubic lattices; random sample values so that a wrong corner cannot go unnoticed; every query compared."""
+    v = vigo_handle
+    rng = np.random.default_rng(sum(shape))
+    dist = rng.normal(size=shape).astype(np.float32)
+    origin, res = np.array([-0.35, 0.2, 1.0]), 0.25
+    v.set_esdf(to_dev(dist, v.device), origin, res)
+    hi = origin + res * np.array(shape)
+    pts = rng.uniform(origin - 0.6, hi + 0.6, size=(4000, 3))
+    # exact cell borders, the first and the last sample of every axis
+    pts[:50] = origin + res * (rng.integers(0, np.array(shape) + 1, size=(50, 3)) + 0.5)
+    pts[50] = origin + 0.5 * res
+    pts[51] = hi - 0.5 * res
+    d, g = v.esdf_query(to_dev(pts, v.device))
+    d_ref, g_ref = ol.esdf_query_batch(dist, origin, res, pts)
+    assert np.array_equal(d.cpu().numpy(), d_ref) and np.array_equal(g.cpu().numpy(), g_ref)
+
+
 def test_stale_hip_error_of_another_library_is_not_reported(vigo_handle):
     """The launchers report hipGetLastError(); an error another library of the process left in that slot
     (found by tools/fuzz_map_gates.py: torch had left one before the first vigo call of a fresh process)

@@ -17,7 +17,7 @@ for k in esdf corridor; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${k}_write -- python3 tools/time_$k.py > $O/${k}_write.json 2> $O/${k}_write.err || echo "$k write failed"
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/${k}_sq -- python3 tools/time_$k.py > $O/${k}_sq.json 2> $O/${k}_sq.err || echo "$k sq failed"
 done
-python3 tools/summarize_pmc.py $O/pmc_esdf.json k_esdf_query $O/esdf_fetch $O/esdf_write $O/esdf_sq > /dev/null
+python3 tools/summarize_pmc.py --halves $O/pmc_esdf.json k_esdf_query $O/esdf_fetch $O/esdf_write $O/esdf_sq > /dev/null
 python3 tools/summarize_pmc.py $O/pmc_corridor.json k_corridor $O/corridor_fetch $O/corridor_write $O/corridor_sq > /dev/null
 python3 bench.py > $O/bench.json 2> $O/bench.err
 ls $O gpurun_out/prof_r2 gpurun_out/prof_r2_fast | head -60

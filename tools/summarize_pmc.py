@@ -1,7 +1,7 @@
 """Summarises rocprofv3 --pmc passes (counter_collection.csv files) of `python bench.py ...` into the
 JSON bench.py reads for roofline.traffic (profiles/pmc_<workload>_<precision>.json).
 
-    python tools/summarize_pmc.py OUT.json KERNEL_SUBSTR DIR_FETCH DIR_WRITE [DIR_SQ]
+    python tools/summarize_pmc.py [--halves] OUT.json KERNEL_SUBSTR DIR_FETCH DIR_WRITE [DIR_SQ]
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950 FETCH_SIZE tallies 64 B
 per 128-B request (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact.  Averages are taken over
@@ -39,6 +39,26 @@ def collect(d, kernel):
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
+def collect_halves(d, kernel):
+    """FETCH_SIZE / WRITE_SIZE averages of the first and of the second half of the kernel's dispatches, in dispatch order
+    (tools/time_esdf.py launches on uniformly random queries first, then on the same queries brick-sorted)"""
+    out = {}
+    for f in glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True):
+        per_dispatch = defaultdict(lambda: defaultdict(float))
+        con = sqlite3.connect(f)
+        for disp, name, cname, val in con.execute("select dispatch_id, kernel_name, counter_name, value from counters_collection"):
+            if kernel in name:
+                per_dispatch[int(disp)][cname] += float(val)
+        ids = sorted(per_dispatch)
+        h = len(ids) // 2
+        for label, part in (("first_half", ids[:h]), ("second_half", ids[h:])):
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals = [per_dispatch[i][c] for i in part if c in per_dispatch[i]]
+                if vals:
+                    out.setdefault(label, {})[c + "_KiB_raw"] = sum(vals) / len(vals)
+    return out
+
+
 def kernel_stats_csv(trace_dir, out_csv):
     """the --stats table (name, calls, total ns, average ns, %) of a --kernel-trace run, as CSV"""
     for f in glob.glob(os.path.join(trace_dir, "**", "*_results.db"), recursive=True):
@@ -59,6 +79,9 @@ def main():
         for r in kernel_stats_csv(sys.argv[2], sys.argv[3])[:5]:
             print(r)
         return
+    halves = "--halves" in sys.argv
+    if halves:
+        sys.argv.remove("--halves")
     out, kernel, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
     merged = {}
     for d in dirs:
@@ -77,6 +100,11 @@ def main():
         "hbm_bytes_per_launch": int(round((2.0 * fetch_kib + write_kib) * 1024.0)),
         "counters_per_launch": {k: v for k, (v, _) in merged.items() if k not in ("FETCH_SIZE", "WRITE_SIZE")},
     }
+    if halves:
+        res["split"] = {}
+        for d in dirs:
+            for label, vals in collect_halves(d, kernel).items():
+                res["split"].setdefault(label, {}).update(vals)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 

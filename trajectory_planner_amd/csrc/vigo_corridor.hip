@@ -533,6 +533,8 @@ __global__ void k_box_points(GridView g, int64_t M, const double* __restrict__ p
 }
 
 // ---- trilinear ESDF (own definition, see oracle/vigo_oracle.c vgo_esdf_query) ------------
+// One query per lane (two or four per lane with all their corner loads in flight measured the same: the gather is
+// bound by the lines it touches, not by latency).  The eight corners of a cell are one base address + constants.
 __global__ void k_esdf_query(EsdfView E, int64_t Q, const double* __restrict__ pts,
                              double* __restrict__ out_d, double* __restrict__ out_g) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -551,22 +553,17 @@ __global__ void k_esdf_query(EsdfView E, int64_t Q, const double* __restrict__ p
         i0[a] = i;
         f[a] = fr;
     }
-    // brick address of (x, y, z) = ax(x) + ay(y) + az(z): per-axis parts, eight sums
-    size_t ax[2], ay[2], az[2];
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-        const int x = i0[0] + d, y = i0[1] + d, z = i0[2] + d;
-        ax[d] = (size_t)(x >> 2) * E.nby * E.nbz * 64 + (size_t)((x & 3) << 4);
-        ay[d] = (size_t)(y >> 2) * E.nbz * 64 + (size_t)((y & 3) << 2);
-        az[d] = (size_t)(z >> 2) * 64 + (size_t)(z & 3);
-    }
+    // cell (x, y, z) lies wholly in brick (x / 3, y / 3, z / 3); its corners are 16 dx + 4 dy + dz further on
+    const unsigned bx = (unsigned)i0[0] / 3u, by = (unsigned)i0[1] / 3u, bz = (unsigned)i0[2] / 3u;
+    const unsigned lx = (unsigned)i0[0] - 3u * bx, ly = (unsigned)i0[1] - 3u * by, lz = (unsigned)i0[2] - 3u * bz;
+    const float* cell = E.dist + (((size_t)bx * E.nby + by) * E.nbz + bz) * 64 + (lx * 16 + ly * 4 + lz);
     double v[2][2][2];
 #pragma unroll
     for (int dx = 0; dx < 2; ++dx)
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
-            v[dx][dy][0] = (double)E.dist[ax[dx] + ay[dy] + az[0]];
-            v[dx][dy][1] = (double)E.dist[ax[dx] + ay[dy] + az[1]];
+            v[dx][dy][0] = (double)cell[dx * 16 + dy * 4];
+            v[dx][dy][1] = (double)cell[dx * 16 + dy * 4 + 1];
         }
     const double c00 = v[0][0][0] * (1 - f[0]) + v[1][0][0] * f[0];
     const double c01 = v[0][0][1] * (1 - f[0]) + v[1][0][1] * f[0];
@@ -585,7 +582,8 @@ __global__ void k_esdf_query(EsdfView E, int64_t Q, const double* __restrict__ p
     out_g[q * 3 + 2] = (c1 - c0) / E.res;
 }
 
-// one thread per destination float (coalesced writes); bricks past the lattice edge are zero-filled, never read
+// one thread per destination float (coalesced writes); values past the lattice edge are zero-filled, never read.
+// Brick b starts at value 3b of each axis (neighbours share a plane of values).
 __global__ void k_esdf_brick(int nx, int ny, int nz, int nby, int nbz, size_t total, const float* __restrict__ src,
                              float* __restrict__ dst) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -593,7 +591,7 @@ __global__ void k_esdf_brick(int nx, int ny, int nz, int nby, int nbz, size_t to
     const size_t brick = i >> 6;
     const int in = (int)(i & 63);
     const int bz = (int)(brick % nbz), by = (int)((brick / nbz) % nby), bx = (int)(brick / ((size_t)nbz * nby));
-    const int x = bx * 4 + (in >> 4), y = by * 4 + ((in >> 2) & 3), z = bz * 4 + (in & 3);
+    const int x = bx * 3 + (in >> 4), y = by * 3 + ((in >> 2) & 3), z = bz * 3 + (in & 3);
     dst[i] = (x < nx && y < ny && z < nz) ? src[((size_t)x * ny + y) * nz + z] : 0.0f;
 }
 
@@ -602,8 +600,8 @@ __global__ void k_esdf_brick(int nx, int ny, int nz, int nby, int nbz, size_t to
 int launch_esdf_brick(hipStream_t s, int nx, int ny, int nz, const float* src, float* dst) {
     const size_t total = esdf_bricked_floats(nx, ny, nz);
     const int block = 256;
-    hipLaunchKernelGGL(k_esdf_brick, dim3((unsigned)((total + block - 1) / block)), dim3(block), 0, s, nx, ny, nz, (ny + 3) / 4,
-                       (nz + 3) / 4, total, src, dst);
+    hipLaunchKernelGGL(k_esdf_brick, dim3((unsigned)((total + block - 1) / block)), dim3(block), 0, s, nx, ny, nz,
+                       esdf_bricks_along(ny), esdf_bricks_along(nz), total, src, dst);
     return (int)hipGetLastError();
 }
 

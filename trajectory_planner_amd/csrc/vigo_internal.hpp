@@ -72,9 +72,11 @@ struct GridView {
     int key0[3];  // octomap key of voxel index 0 minus 32768 (corridor checker)
 };
 
-// ESDF samples in HBM as 4x4x4 bricks (256 B, z fastest inside a brick, bricks z fastest): the eight corners of
-// a trilinear cell fall into 2.3 cache lines on average instead of 4.1 for the row-major lattice, which is what
-// bounds uniformly random queries (the lattice lives in the Infinity Cache, not in L2).
+// ESDF samples in HBM as OVERLAPPING bricks of 4x4x4 values (256 B = two 128-B lines, z fastest inside a brick, bricks
+// z fastest): brick b holds the values 3b .. 3b+3 of each axis, i.e. 3x3x3 whole trilinear cells, at 2.37x the memory
+// of the lattice.  Uniformly random queries are bound by the cache lines they touch (a 256^3 lattice lives in the
+// Infinity Cache, not in L2): the row-major lattice costs 4.1 lines per cell, disjoint 4x4x4 bricks 2.3, these 1.33 —
+// all eight corners of a cell in one brick, and in one line unless the cell is the middle one along x.
 struct EsdfView {
     const float* dist;        // bricked copy, nbx * nby * nbz * 64 floats
     int nx, ny, nz;
@@ -82,8 +84,9 @@ struct EsdfView {
     double origin[3];
     double res;
 };
+inline int esdf_bricks_along(int n) { return (n + 1) / 3; }   // ceil((n - 1) / 3) bricks cover the n - 1 cells, n >= 2
 inline size_t esdf_bricked_floats(int nx, int ny, int nz) {
-    return (size_t)((nx + 3) / 4) * ((ny + 3) / 4) * ((nz + 3) / 4) * 64;
+    return (size_t)esdf_bricks_along(nx) * esdf_bricks_along(ny) * esdf_bricks_along(nz) * 64;
 }
 
 // Per-handle (= per-device) launch state: which kernel instantiations already had their dynamic-LDS limit raised on
