@@ -389,7 +389,7 @@ double vigo_exact_pow_integer(double t, int d);
 
 /* ---- ESDF trilinear query (config 5; no reference counterpart) -------
  * vigo_set_esdf copies the row-major float lattice dist_dev[nx][ny][nz] (device memory) into the handle's own layout
- * (overlapping 4x4x4 bricks): 2.37x the lattice's bytes of device memory, stream-ordered, the caller's
+ * (one 128-B line per group of 1x3x3 trilinear cells): 3.56x the lattice's bytes of device memory, stream-ordered, the caller's
  * buffer is not referenced afterwards.  nx, ny, nz >= 2. */
 
 int vigo_set_esdf(vigo_handle_t h, int nx, int ny, int nz, const double origin[3],

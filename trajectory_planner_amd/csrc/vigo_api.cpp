@@ -662,7 +662,7 @@ int vigo_box_collision_points(vigo_handle_t h, int64_t M, const double* pts, con
 int vigo_set_esdf(vigo_handle_t h, int nx, int ny, int nz, const double origin[3], double res, const float* dist_dev) {
     if (!h || !dist_dev || !origin || nx < 2 || ny < 2 || nz < 2 || !geometry_ok(origin, res)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_esdf: bad argument");
     if ((long long)nx * ny * nz > (1LL << 33)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_set_esdf: lattice too large");
-    size_t bytes = vigo::esdf_bricked_floats(nx, ny, nz) * sizeof(float);   // 2.37x the lattice (overlapping bricks)
+    size_t bytes = vigo::esdf_bricked_floats(nx, ny, nz) * sizeof(float);   // 3.56x the lattice (one line per cell group)
     if (bytes > h->esdf_capacity) {
         if (h->esdf) (void)hipFree(h->esdf);
         h->esdf = nullptr;
@@ -670,7 +670,7 @@ int vigo_set_esdf(vigo_handle_t h, int nx, int ny, int nz, const double origin[3
         VIGO_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->esdf), bytes));
         h->esdf_capacity = bytes;
     }
-    VIGO_HIP(h, (hipError_t)vigo::launch_esdf_brick(h->stream, nx, ny, nz, dist_dev, h->esdf));   // row-major -> bricks
+    VIGO_HIP(h, (hipError_t)vigo::launch_esdf_brick(h->stream, nx, ny, nz, dist_dev, h->esdf));   // row-major -> one line per cell group
     h->esdf_view.dist = h->esdf;
     h->esdf_view.nx = nx; h->esdf_view.ny = ny; h->esdf_view.nz = nz;
     h->esdf_view.nby = vigo::esdf_bricks_along(ny); h->esdf_view.nbz = vigo::esdf_bricks_along(nz);

@@ -553,10 +553,10 @@ __global__ void k_esdf_query(EsdfView E, int64_t Q, const double* __restrict__ p
         i0[a] = i;
         f[a] = fr;
     }
-    // cell (x, y, z) lies wholly in brick (x / 3, y / 3, z / 3); its corners are 16 dx + 4 dy + dz further on
-    const unsigned bx = (unsigned)i0[0] / 3u, by = (unsigned)i0[1] / 3u, bz = (unsigned)i0[2] / 3u;
-    const unsigned lx = (unsigned)i0[0] - 3u * bx, ly = (unsigned)i0[1] - 3u * by, lz = (unsigned)i0[2] - 3u * bz;
-    const float* cell = E.dist + (((size_t)bx * E.nby + by) * E.nbz + bz) * 64 + (lx * 16 + ly * 4 + lz);
+    // cell (x, y, z) reads line (x, y / 3, z / 3); its corners are 16 dx + 4 dy + dz further on
+    const unsigned by = (unsigned)i0[1] / 3u, bz = (unsigned)i0[2] / 3u;
+    const unsigned ly = (unsigned)i0[1] - 3u * by, lz = (unsigned)i0[2] - 3u * bz;
+    const float* cell = E.dist + (((size_t)i0[0] * E.nby + by) * E.nbz + bz) * 32 + (ly * 4 + lz);
     double v[2][2][2];
 #pragma unroll
     for (int dx = 0; dx < 2; ++dx)
@@ -583,15 +583,15 @@ __global__ void k_esdf_query(EsdfView E, int64_t Q, const double* __restrict__ p
 }
 
 // one thread per destination float (coalesced writes); values past the lattice edge are zero-filled, never read.
-// Brick b starts at value 3b of each axis (neighbours share a plane of values).
+// Line (x, by, bz) holds the values [x, x + 1] x [3 by, 3 by + 3] x [3 bz, 3 bz + 3], z fastest.
 __global__ void k_esdf_brick(int nx, int ny, int nz, int nby, int nbz, size_t total, const float* __restrict__ src,
                              float* __restrict__ dst) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const size_t brick = i >> 6;
-    const int in = (int)(i & 63);
-    const int bz = (int)(brick % nbz), by = (int)((brick / nbz) % nby), bx = (int)(brick / ((size_t)nbz * nby));
-    const int x = bx * 3 + (in >> 4), y = by * 3 + ((in >> 2) & 3), z = bz * 3 + (in & 3);
+    const size_t line = i >> 5;
+    const int r = (int)(i & 31);
+    const int bz = (int)(line % nbz), by = (int)((line / nbz) % nby);
+    const int x = (int)(line / ((size_t)nbz * nby)) + (r >> 4), y = by * 3 + ((r >> 2) & 3), z = bz * 3 + (r & 3);
     dst[i] = (x < nx && y < ny && z < nz) ? src[((size_t)x * ny + y) * nz + z] : 0.0f;
 }
 

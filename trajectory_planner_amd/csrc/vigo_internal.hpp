@@ -72,21 +72,21 @@ struct GridView {
     int key0[3];  // octomap key of voxel index 0 minus 32768 (corridor checker)
 };
 
-// ESDF samples in HBM as OVERLAPPING bricks of 4x4x4 values (256 B = two 128-B lines, z fastest inside a brick, bricks
-// z fastest): brick b holds the values 3b .. 3b+3 of each axis, i.e. 3x3x3 whole trilinear cells, at 2.37x the memory
-// of the lattice.  Uniformly random queries are bound by the cache lines they touch (a 256^3 lattice lives in the
-// Infinity Cache, not in L2): the row-major lattice costs 4.1 lines per cell, disjoint 4x4x4 bricks 2.3, these 1.33 —
-// all eight corners of a cell in one brick, and in one line unless the cell is the middle one along x.
+// ESDF samples in HBM as one 128-B cache line per group of trilinear cells: line (x, by, bz) holds the 2 x 4 x 4 values
+// [x, x+1] x [3 by, 3 by + 3] x [3 bz, 3 bz + 3] (z fastest), i.e. the 1 x 3 x 3 whole cells starting at (x, 3 by, 3 bz):
+// all eight corners of ANY cell lie in ONE line (one base address + constant offsets), at 3.56x the lattice's bytes.
+// Uniformly random queries are bound by the cache lines they touch (a 256^3 lattice lives in the Infinity Cache, not
+// in L2): the row-major lattice costs 4.1 lines per cell, disjoint 4x4x4 bricks 2.3, overlapping 4x4x4 bricks 1.33.
 struct EsdfView {
-    const float* dist;        // bricked copy, nbx * nby * nbz * 64 floats
+    const float* dist;        // (nx - 1) * nby * nbz lines of 32 floats
     int nx, ny, nz;
-    int nby, nbz;             // bricks along y and z
+    int nby, nbz;             // lines along y and z
     double origin[3];
     double res;
 };
-inline int esdf_bricks_along(int n) { return (n + 1) / 3; }   // ceil((n - 1) / 3) bricks cover the n - 1 cells, n >= 2
+inline int esdf_bricks_along(int n) { return (n + 1) / 3; }   // ceil((n - 1) / 3) groups cover the n - 1 cells, n >= 2
 inline size_t esdf_bricked_floats(int nx, int ny, int nz) {
-    return (size_t)esdf_bricks_along(nx) * esdf_bricks_along(ny) * esdf_bricks_along(nz) * 64;
+    return (size_t)(nx - 1) * esdf_bricks_along(ny) * esdf_bricks_along(nz) * 32;
 }
 
 // Per-handle (= per-device) launch state: which kernel instantiations already had their dynamic-LDS limit raised on
