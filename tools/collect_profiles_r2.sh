@@ -10,7 +10,8 @@ O=gpurun_out/r2prof
 mkdir -p $O
 bash tools/collect_profiles.sh r2 > $O/collect_r2.log 2>&1 || echo "collect r2 failed"
 bash tools/collect_profiles.sh r2_fast --precision f64_fast > $O/collect_r2_fast.log 2>&1 || echo "collect r2_fast failed"
-rocprofv3 --kernel-trace --stats -d $O/all_trace -- python3 tools/measure_configs.py > $O/configs.jsonl 2> $O/configs.err || echo "configs trace failed"
+rocprofv3 --kernel-trace --stats -d $O/all_trace -- python3 tools/measure_configs.py > $O/configs.out 2> $O/configs.err || echo "configs trace failed"
+grep "^{" $O/configs.out > $O/configs.jsonl   # (the C++ facade prints its own lines to stdout)
 python3 tools/summarize_pmc.py --kernel-stats $O/all_trace $O/allkernels_stats.csv > /dev/null
 for k in esdf corridor; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${k}_fetch -- python3 tools/time_$k.py > $O/${k}_fetch.json 2> $O/${k}_fetch.err || echo "$k fetch failed"
