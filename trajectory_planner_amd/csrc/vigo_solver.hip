@@ -401,7 +401,7 @@ __device__ __forceinline__ void obstacle_term_tab(const DevConst& K, const T (&c
 // (the line search needs g.d after every evaluation, LB:829, and the norms after the last one,
 // LB:1200-1201; fusing them costs three more DPP chains instead of two more reductions).
 // Returns the weighted total cost (group-uniform).
-template <typename T, int GROUP, int PPL, bool FAST>
+template <typename T, int GROUP, int PPL, bool FAST, bool OBS = true>
 __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LaneProblem<T, PPL>& Q,
                                                  const T (&c)[PPL][3], const T (&d)[PPL][3], T (&g)[PPL][3],
                                                  double (&sums)[7]) {
@@ -535,8 +535,8 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
         }
     }
 
-    // ---- dynamic obstacles, BT.cpp:1001-1064 ----
-    if (Q.o_end > Q.o_begin) {
+    // ---- dynamic obstacles, BT.cpp:1001-1064 (OBS == false: an instantiation for calls without an obstacle list) ----
+    if (OBS && Q.o_end > Q.o_begin) {
 #pragma unroll
         for (int q = 0; q < PPL; ++q) {
             if (!Q.interior[q]) continue;
@@ -574,7 +574,14 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
             part[4] += v4; part[5] += v5; part[6] += v6;
         }
     }
-    group_sum<GROUP, 7>(part);
+    if (OBS) {
+        group_sum<GROUP, 7>(part);
+    } else {
+        // no obstacles: the dynamic cost is a sum of zeros — 0.0, as the reduction would return — so it stays out of it
+        double p6[6] = {part[0], part[1], part[2], part[4], part[5], part[6]};
+        group_sum<GROUP, 6>(p6);
+        part[0] = p6[0]; part[1] = p6[1]; part[2] = p6[2]; part[3] = 0.0; part[4] = p6[3]; part[5] = p6[4]; part[6] = p6[5];
+    }
 #pragma unroll
     for (int q = 0; q < 7; ++q) sums[q] = part[q];
     return ((Q.w[0] * part[0] + Q.w[1] * part[1]) + Q.w[2] * part[2]) + Q.w[3] * part[3];
@@ -840,7 +847,9 @@ __device__ __forceinline__ int trial_interval(double& xt, double& xf, double& xd
 // or fp64 trajectories of up to ~21 control points): capping the registers at 256 (a few hundred bytes of
 // scratch per lane) then lets two waves share a SIMD's issue slots — +17 % for fp32 at 65 536 x 32, +36 % for
 // fp64 at 16 384 x 16 — but costs 6 % when every wave has a SIMD to itself anyway.  Same arithmetic, same bits.
-template <typename T, int GROUP, int PPL, bool FAST, int WPS = 1>
+// OBS == false: the instantiation the launcher picks for calls without an obstacle list (A.obs == nullptr): no staging
+// code, no obstacle loop, six sums per evaluation instead of seven — the same bits, fewer live registers
+template <typename T, int GROUP, int PPL, bool FAST, int WPS = 1, bool OBS = true>
 __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevConst* __restrict__ Kp) {
     const DevConst& K = *Kp;  // uniform address: scalar loads at the use sites, not 100+ live SGPRs
     constexpr int TPB = kWave / GROUP;
@@ -901,7 +910,8 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
         return *reinterpret_cast<HPair<T>*>(reinterpret_cast<char*>(hl[q]) + (size_t)slot * slotB);
     };
     auto ys_at = [&](int slot) -> YS& { return *reinterpret_cast<YS*>(reinterpret_cast<char*>(ys_l) + (size_t)slot * slotB); };
-    if (A.obs) {
+    if (!OBS) { Q.obs = nullptr; Q.o_begin = Q.o_end = 0; }
+    if (OBS && A.obs) {
         // stage this trajectory's obstacles once: the predicted positions and thresholds of
         // BT.cpp:1011-1020 by the expressions of obstacle_term(), sizes in T arithmetic
         constexpr int kEnt = kObsTabEntries<GROUP>;
@@ -1000,7 +1010,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
             }
 
             VIGO_TICK(t_pre);
-            fx = eval_cost_grad<T, GROUP, PPL, FAST>(K, Q, x, d, g, sums);  // the only evaluation site (LB:828, :1132)
+            fx = eval_cost_grad<T, GROUP, PPL, FAST, OBS>(K, Q, x, d, g, sums);  // the only evaluation site (LB:828, :1132)
             VIGO_TICK(t_eval);
             ++evals;
             if (first) break;
@@ -1350,6 +1360,11 @@ constexpr size_t kLdsPerWorkgroup = 160 * 1024;
 
 }  // namespace
 
+#ifndef VIGO_SOLVER_PART
+#define VIGO_SOLVER_PART 0
+#endif
+
+#if VIGO_SOLVER_PART == 0
 DevConst make_dev_const(const vigo_params_t& P) {
     DevConst K{};
     K.dth = P.dthresh;
@@ -1385,9 +1400,12 @@ DevConst make_dev_const(const vigo_params_t& P) {
     return K;
 }
 
+#endif  // VIGO_SOLVER_PART == 0
+
 // (GROUP, PPL) for N control points: 32 x 1 up to 32, then 64 x {1, 2, 4}
 static inline int shape_for(int N) { return N <= 32 ? 0 : (N <= 64 ? 1 : (N <= 128 ? 2 : 3)); }
 
+#if VIGO_SOLVER_PART == 0
 template <typename T, bool FAST>
 static int launch_cost_grad_t(hipStream_t s, const SolveArgs& a, const DevConst* kd) {
     const int shape = shape_for(a.N);
@@ -1409,6 +1427,7 @@ int launch_cost_grad(hipStream_t s, const SolveArgs& a, const DevConst& k, const
     if (precision == VIGO_PREC_F64_FAST) return launch_cost_grad_t<double, true>(s, a, kd);
     return launch_cost_grad_t<double, false>(s, a, kd);
 }
+#endif  // VIGO_SOLVER_PART == 0
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: the "already raised" flags live in the handle
 // (LaunchState, one per handle = per device), never in function statics, so a second device of the same process
@@ -1423,48 +1442,63 @@ static int raise_dynamic_lds(LaunchState& L, int slot, KernelT kernel) {
     return (int)hipSuccess;
 }
 
-template <typename T, int GROUP, int PPL, bool FAST>
+template <typename T, int GROUP, int PPL, bool FAST, bool OBS>
 static int launch_optimize_t(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, LaunchState& L) {
     const int tpb = kWave / GROUP;
     const size_t lds = optimize_lds_bytes<T, GROUP, FAST>(a.N, k.mem_size, PPL, a.obs != nullptr);
     if (lds > kLdsPerWorkgroup) return (int)hipErrorInvalidValue;  // refused earlier by vigo_optimize
     dim3 grid((a.B + tpb - 1) / tpb), block(kWave);
-    // slot = arithmetic (fp32 / fp64 / fp64 fast) x shape (GROUP, PPL) x waves per SIMD
+    // slot = arithmetic (fp32 / fp64 / fp64 fast) x shape (GROUP, PPL) x waves per SIMD x with / without obstacles
     const int arith = std::is_same<T, float>::value ? 0 : (FAST ? 2 : 1);
     const int shape = GROUP == 32 ? 0 : (PPL == 1 ? 1 : (PPL == 2 ? 2 : 3));
-    const int slot = (arith * 4 + shape) * 2;
+    const int slot = (arith * 4 + shape) * 4;
     // a solver wavefront per SIMD (4 per CU) is full occupancy for these kernels; unknown SIMD count: never switch
     const int simds = L.simd_count > 0 ? L.simd_count : (1 << 30);
-    if constexpr (PPL == 1) if ((int)grid.x > simds && lds <= kLdsPerWorkgroup / 8) {   // more waves than SIMDs and 8 fit a CU: two per SIMD
-        int e = raise_dynamic_lds(L, slot + 1, &k_optimize<T, GROUP, PPL, FAST, 2>);
+    auto go = [&](auto kernel, int sl) -> int {
+        int e = raise_dynamic_lds(L, sl, kernel);
         if (e != (int)hipSuccess) return e;
-        hipLaunchKernelGGL((k_optimize<T, GROUP, PPL, FAST, 2>), grid, block, lds, s, a, kd);
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, kd);
         return (int)hipGetLastError();
+    };
+    if constexpr (PPL == 1) if ((int)grid.x > simds && lds <= kLdsPerWorkgroup / 8) {   // more waves than SIMDs and 8 fit a CU: two per SIMD
+        return go(&k_optimize<T, GROUP, PPL, FAST, 2, OBS>, slot + (OBS ? 1 : 3));
     }
-    int e = raise_dynamic_lds(L, slot, &k_optimize<T, GROUP, PPL, FAST>);
-    if (e != (int)hipSuccess) return e;
-    hipLaunchKernelGGL((k_optimize<T, GROUP, PPL, FAST>), grid, block, lds, s, a, kd);
-    return (int)hipGetLastError();
+    return go(&k_optimize<T, GROUP, PPL, FAST, 1, OBS>, slot + (OBS ? 0 : 2));
 }
 
-template <typename T, bool FAST>
+template <typename T, bool FAST, bool OBS>
 static int launch_optimize_p(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, LaunchState& L) {
     // (one trajectory per wave for N <= 32 — 64 x 1 with half the lanes idle, no divergence between
     // the two line searches — measured slower: 0.462 vs 0.445 ms at B = 1024, 6.40 vs 3.60 ms at B = 16384)
     switch (shape_for(a.N)) {
         // (a 16-lane x 2-point shape saves one butterfly level but measured 22 % slower: 1.76 M vs 2.26 M/s)
-        case 0: return launch_optimize_t<T, 32, 1, FAST>(s, a, k, kd, L);
-        case 1: return launch_optimize_t<T, 64, 1, FAST>(s, a, k, kd, L);
-        case 2: return launch_optimize_t<T, 64, 2, FAST>(s, a, k, kd, L);
-        default: return launch_optimize_t<T, 64, 4, FAST>(s, a, k, kd, L);
+        case 0: return launch_optimize_t<T, 32, 1, FAST, OBS>(s, a, k, kd, L);
+        case 1: return launch_optimize_t<T, 64, 1, FAST, OBS>(s, a, k, kd, L);
+        case 2: return launch_optimize_t<T, 64, 2, FAST, OBS>(s, a, k, kd, L);
+        default: return launch_optimize_t<T, 64, 4, FAST, OBS>(s, a, k, kd, L);
     }
 }
 
+template <bool OBS>
+static int launch_optimize_o(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, int precision, LaunchState& L) {
+    if (precision == VIGO_PREC_F32) return launch_optimize_p<float, false, OBS>(s, a, k, kd, L);
+    if (precision == VIGO_PREC_F64_FAST) return launch_optimize_p<double, true, OBS>(s, a, k, kd, L);
+    return launch_optimize_p<double, false, OBS>(s, a, k, kd, L);
+}
+
+// This file is compiled TWICE (csrc/Makefile).  VIGO_SOLVER_PART == 1: only the k_optimize instantiations for calls WITH
+// an obstacle list, built with machine LICM (their inner obstacle loops want their invariants hoisted: 1.85 vs 1.92 ms on
+// config 5a); VIGO_SOLVER_PART == 0: everything else, built without it (-3 % on configs 2 and 4).
+#if VIGO_SOLVER_PART == 1
+int launch_optimize_with_obstacles(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, int precision, LaunchState& L) {
+    return launch_optimize_o<true>(s, a, k, kd, precision, L);
+}
+#else
+int launch_optimize_with_obstacles(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, int precision, LaunchState& L);
 int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, int precision, LaunchState& L) {
     if (a.B <= 0) return hipSuccess;
-    if (precision == VIGO_PREC_F32) return launch_optimize_p<float, false>(s, a, k, kd, L);
-    if (precision == VIGO_PREC_F64_FAST) return launch_optimize_p<double, true>(s, a, k, kd, L);
-    return launch_optimize_p<double, false>(s, a, k, kd, L);
+    if (a.obs != nullptr) return launch_optimize_with_obstacles(s, a, k, kd, precision, L);
+    return launch_optimize_o<false>(s, a, k, kd, precision, L);
 }
 
 // bytes of LDS one trajectory-solve workgroup needs; the C ABI refuses N it cannot hold
@@ -1475,5 +1509,6 @@ size_t optimize_lds_requirement(int N, int mem_size, int precision) {
     if (precision == VIGO_PREC_F64_FAST) return g32 ? optimize_lds_bytes<double, 32, true>(N, mem_size, ppl, true) : optimize_lds_bytes<double, 64, true>(N, mem_size, ppl, true);
     return g32 ? optimize_lds_bytes<double, 32, false>(N, mem_size, ppl, true) : optimize_lds_bytes<double, 64, false>(N, mem_size, ppl, true);
 }
+#endif  // VIGO_SOLVER_PART
 
 }  // namespace vigo
