@@ -10,7 +10,8 @@ from trajectory_planner_amd.vigo import Vigo, default_params
 dev = torch.device("cuda", 0)
 T = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 w256 = synth.make_box_world(synth.SEED_BASE + 2, n=256, n_boxes=200)
-for (B, N, prec) in ((1024, 32, 0), (1024, 32, 2), (16384, 32, 0), (8192, 64, 0)):
+CASES = ((1024, 32, 0), (1024, 32, 2), (16384, 32, 0), (8192, 64, 0)) if not os.environ.get('VIGO_EXP_MATRIX') else tuple((B, N, p) for (B, N) in ((16384, 16), (1024, 32), (16384, 32), (8192, 64), (4096, 128), (2048, 200)) for p in (0, 2, 1))
+for (B, N, prec) in CASES:
     b = synth.make_bspline_batch(w256, B, N, 4242 + N + B, start_range=8.0)
     P = default_params(); P.max_iterations = 50
     v = Vigo(0, P, prec)

@@ -1498,6 +1498,11 @@ int launch_optimize_with_obstacles(hipStream_t s, const SolveArgs& a, const DevC
 int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, int precision, LaunchState& L) {
     if (a.B <= 0) return hipSuccess;
     if (a.obs != nullptr) return launch_optimize_with_obstacles(s, a, k, kd, precision, L);
+    // Measured (tools/exp_solver.py, VIGO_EXP_MATRIX=1: N = 16 ... 200 x the three arithmetic modes): the instantiation
+    // without obstacle code is 4 - 18 % faster everywhere except f64_fast at 32 < N <= 64 on batches with more waves
+    // than SIMDs (8 % slower there): those keep the general kernel, which treats a missing list as no obstacles.
+    if (precision == VIGO_PREC_F64_FAST && a.N > 32 && a.N <= 64 && L.simd_count > 0 && a.B > L.simd_count)
+        return launch_optimize_with_obstacles(s, a, k, kd, precision, L);
     return launch_optimize_o<false>(s, a, k, kd, precision, L);
 }
 
