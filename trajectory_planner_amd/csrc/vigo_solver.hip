@@ -1165,7 +1165,9 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
             constexpr bool STEADY = decltype(steady_tag)::value;
             constexpr bool MARK = STEADY && !FAST && VIGO_TWOLOOP_MARKSTEIN;
             double amin = 1.0, amax = 1.0;
-            const int bnd = STEADY ? kMaxMem : bound;
+            // (general path: every live lane of the wave is in the same iteration, so the number of pairs is taken
+            // through an SGPR — `age < bnd` becomes a scalar branch instead of a compare + exec-mask block per step)
+            const int bnd = STEADY ? kMaxMem : __builtin_amdgcn_readfirstlane(bound);
             double al_reg[STEADY ? kMaxMem : 1];
             // STEADY: the LDS ring (kMaxMem - 2 slots) is walked with running byte offsets — one
             // add and a wrap per fetch instead of slot arithmetic and two quarter-rate multiplies
