@@ -1202,7 +1202,11 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
             Pys[0] = ys_div;
 #pragma unroll
             for (int age = 1; age < kWin; ++age)
-                if (age < bnd) fetch(age, Ps[age], Py[age], Pys[age]);
+                if (age < bnd) {
+                    // (a window of more than two pairs starts with ring slots in it: the ring pointer moves with them)
+                    if (STEADY && age >= 2) { ring_fetch(Ps[age], Py[age], Pys[age]); ring_older(); }
+                    else fetch(age, Ps[age], Py[age], Pys[age]);
+                }
 #pragma unroll
             for (int age = 0; age < kMaxMem; ++age) {      // newest -> oldest, LB:1294-1303
                 if (age < bnd) {
