@@ -4,6 +4,9 @@ covered by tests/ -m gpu; this script only times."""
 import json, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np, torch
+import trajectory_planner_amd._lib as _L
+if os.environ.get("VIGO_EXP_LIB"):   # dev: A/B another build of the library
+    _L.LIB_PATH = os.path.join(R, os.environ["VIGO_EXP_LIB"])
 from trajectory_planner_amd import synth
 from trajectory_planner_amd.vigo import PREC_F32, PREC_F64, Vigo, default_params
 
