@@ -169,6 +169,36 @@ def test_line_search_failure_keeps_last_trial_point(vigo_handle, small_world):
     assert np.array_equal(ctrl, e["ctrl"]) and np.array_equal(x, e["x"]) and np.array_equal(st, e["status"])
 
 
+def test_config2_at_the_references_iteration_cap(vigo_handle):
+    """BT.cpp:698 runs the solver with max_iterations = 200; BASELINE config 2 quotes 50.  The control-point statement
+    at the reference's own cap, on the config-2 batch (1024 x 32, 256^3): bit-identical to the emulation-mode oracle (the
+    parity gate proper), and against the reference-order oracle what 200 unconverged iterations leave of a last-bit
+    difference in summation order — measured 70 % of the trajectories within 1e-4, median 4.4e-8, objective reached
+    equal to 2e-9 (median), 97.8 % equal status codes; SURVEY.md §9 measured the same amplification on the CPU alone
+    (an injected relative noise of 1e-15 per evaluation: 1e-3 after 50 iterations in the worst case), so the
+    reference's own result at this setting depends on its compiler and libm to that extent."""
+    v = vigo_handle
+    P = default_params()
+    P.max_iterations = 200
+    v.set_params(P)
+    world, b = synth.config2()
+    v.set_grid(torch.from_numpy(world.voxels).to(v.device), world.origin, world.res)
+    r = v.optimize(**batch_to_dev(b, v.device))
+    g = {k: getattr(r, k).cpu().numpy() for k in ("ctrl", "x", "status", "fx", "iters", "evals")}
+    with emulation(b.N):
+        e = ol.optimize_batch(P, b)
+    for k in ("status", "iters", "evals", "x", "ctrl", "fx"):
+        assert np.array_equal(g[k], e[k]), f"{k} differs from the emulation-mode oracle at 200 iterations"
+    ref = ol.optimize_batch(P, b)
+    rel = rel_err_per_traj(g["ctrl"], ref["ctrl"])
+    frel = np.abs(g["fx"] - ref["fx"]) / np.abs(ref["fx"])
+    print(f"\n[config 2 at 200 iterations] vs reference-order oracle: within 1e-4 {(rel <= TOL).mean():.3f}, median {np.median(rel):.2e}, "
+          f"p90 {np.quantile(rel, .9):.2e}, max {rel.max():.2e}; objective median rel diff {np.median(frel):.2e}; "
+          f"equal status {(g['status'] == ref['status']).mean():.3f}; mean iterations {g['iters'].mean():.1f}")
+    assert np.median(rel) < 1e-6 and (rel <= TOL).mean() >= 0.6
+    assert np.median(frel) < 1e-7 and (g["status"] == ref["status"]).mean() >= 0.95
+
+
 def test_determinism_permutation_and_subbatch_invariance(vigo_handle, small_world):
     """size-independent properties at the BASELINE config-2 size (1024 x 32, 50 iterations):
     re-running gives identical bits; a trajectory's result does not depend on its batch slot."""
