@@ -537,7 +537,13 @@ __global__ void k_box_points(GridView g, int64_t M, const double* __restrict__ p
 // bound by the lines it touches, not by latency).  The eight corners of a cell are one base address + constants.
 __global__ void k_esdf_query(EsdfView E, int64_t Q, const double* __restrict__ pts,
                              double* __restrict__ out_d, double* __restrict__ out_g) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, each XCD has its own L2): block b
+    // takes the tile (b % 8) * (tiles / 8) + b / 8, so that every XCD walks ONE contiguous eighth of the queries — for
+    // spatially coherent queries its L2 then holds lattice lines no other XCD asks for.  (Uniformly random: no effect.)
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const unsigned base = nb >> 3, rem = nb & 7u;
+    const unsigned tile = xcd * base + (xcd < rem ? xcd : rem) + idx;
+    const int64_t q = (int64_t)tile * blockDim.x + threadIdx.x;
     if (q >= Q) return;
     const int n[3] = {E.nx, E.ny, E.nz};
     int i0[3];
