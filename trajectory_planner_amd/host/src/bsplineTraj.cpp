@@ -1043,12 +1043,20 @@ std::vector<bool> bsplineTraj::makePlanBatch(const std::vector<bsplineTraj*>& pl
     // read-only map: the planners are spread over the host cores
     const double tp0 = wallSeconds();
     std::vector<uint8_t> prepared(P, 0);
+    std::atomic<long long> nsSeg{0}, nsAstar{0}, nsGuide{0};   // (summed over the worker threads; printed with VIGO_FACADE_TIMING)
     parallelFor(P, [&](size_t i) {
         bsplineTraj* p = planners[i];
         if (!p->init_ || !p->map_) return;
+        const double t0 = wallSeconds();
         p->findCollisionSeg(p->optData_.controlPoints, p->collisionSeg_);           // step 1
-        if (!p->pathSearch(p->collisionSeg_, p->astarPaths_)) return;               // step 2
+        const double t1 = wallSeconds();
+        const bool found = p->pathSearch(p->collisionSeg_, p->astarPaths_);         // step 2
+        const double t2 = wallSeconds();
+        nsSeg += (long long)((t1 - t0) * 1e9);
+        nsAstar += (long long)((t2 - t1) * 1e9);
+        if (!found) return;
         p->assignGuidePointsSemiCircle(p->astarPaths_, p->collisionSeg_);           // step 3
+        nsGuide += (long long)((wallSeconds() - t2) * 1e9);
         prepared[i] = 1;
     });
     for (size_t i = 0; i < P; ++i) {
@@ -1189,6 +1197,9 @@ std::vector<bool> bsplineTraj::makePlanBatch(const std::vector<bsplineTraj*>& pl
         p->bspline_ = trajPlanner::bspline(bsplineDegree, p->optData_.controlPoints, p->controlPointsTs_);  // step 5
         p->linearFeasibilityReparam();                                                                  // step 6
     });
+    if (getenv("VIGO_FACADE_TIMING"))
+        cout << "[BsplineTraj]: prologue CPU time summed over the workers: findCollisionSeg " << nsSeg.load() * 1e-6 << " ms, A* " << nsAstar.load() * 1e-6
+             << " ms, guide assignment " << nsGuide.load() * 1e-6 << " ms" << endl;
     if (getenv("VIGO_FACADE_TIMING"))
         cout << "[BsplineTraj]: makePlanBatch of " << P << ": prologue " << (tp1 - tp0) * 1e3 << " ms, rebound loop " << (tp2 - tp1) * 1e3
              << " ms, epilogue " << (wallSeconds() - tp2) * 1e3 << " ms" << endl;

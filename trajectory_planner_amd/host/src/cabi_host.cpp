@@ -5,6 +5,7 @@
 #error "tools of the in-tree dense map (standin/dense_occmap.h): not part of a build against map_manager"
 #endif
 #include <trajectory_planner/octomapBt.h>
+#include <trajectory_planner/path_search/astarOcc.h>
 #include <trajectory_planner/polyTrajOctomap.h>
 #include <trajectory_planner/polyTrajSolver.h>
 
@@ -48,6 +49,22 @@ int vigo_host_pcd_load(const char* path, double res, const double* inflate, int 
     if ((long long)m->voxels().size() > cap) return -2;
     std::memcpy(out, m->voxels().data(), m->voxels().size());
     return 0;
+}
+
+// one AStar::AstarSearch on a dense byte grid (bit 0 = inflated-occupied): returns the number of path points written
+// (xyz triples, start side first), -1 when no path is found, -2 when path_out is too small
+int vigo_host_astar(const unsigned char* vox, const int* dims, const double* origin, double res, const int* pool, double min_height,
+                    double max_height, double step, const double* start, const double* end, double* path_out, int cap) {
+    auto m = std::make_shared<mapManager::occMap>(dims[0], dims[1], dims[2], Eigen::Vector3d(origin[0], origin[1], origin[2]), res);
+    std::memcpy(m->voxels().data(), vox, m->voxels().size());
+    AStar a;
+    a.initGridMap(m, Eigen::Vector3i(pool[0], pool[1], pool[2]), min_height, max_height);
+    if (!a.AstarSearch(step, Eigen::Vector3d(start[0], start[1], start[2]), Eigen::Vector3d(end[0], end[1], end[2]))) return -1;
+    const std::vector<Eigen::Vector3d> path = a.getPath();
+    if ((int)path.size() > cap) return -2;
+    for (size_t i = 0; i < path.size(); ++i)
+        for (int k = 0; k < 3; ++k) path_out[3 * i + k] = path[i](k);
+    return (int)path.size();
 }
 
 // min-snap through n_wp waypoints (xyz triples); corridor == NULL: equality-constrained only.
