@@ -25,6 +25,7 @@ def host():
     L.vigo_host_pcd_load.argtypes = [C.c_char_p, C.c_double, _dp, C.c_int, C.c_void_p, C.c_longlong, C.POINTER(C.c_int), _dp,
                                      C.POINTER(C.c_longlong)]
     L.vigo_host_minsnap.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_double, _dp, _dp]
+    L.vigo_host_minsnap_eval.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp]
     return L
 
 
@@ -332,3 +333,34 @@ def test_map_adapter_rasterises_through_the_four_public_methods():
         bad = L.vigo_host_rasterise_check(40, 33, 17, origin.ctypes.data_as(dp), 0.1, vox.ctypes.data_as(C.c_void_p),
                                           lo_a.ctypes.data_as(dp), hi_a.ctypes.data_as(dp), dims)
         assert bad == 0 and tuple(dims) == want, (bad, tuple(dims))
+
+
+def test_polytrajsolver_getvel_getacc_as_the_reference_writes_them(host):
+    """polyTrajSolver::getVel / getAcc (PS.cpp:1080-1122): derivatives of the segment polynomial in local time — with the
+    reference's own exponent in the x component of the acceleration (pow(t, d-1) where y and z use pow(t, d-2),
+    PS.cpp:1112), which a caller of the reference gets and a drop-in therefore returns."""
+    wp = np.array([[0.0, 0.0, 1.0], [1.5, 0.4, 1.2], [2.5, 1.8, 0.9], [4.0, 2.0, 1.0]])
+    deg = 7
+    n = (len(wp) - 1) * (deg + 1)
+    coeffs, knots = np.zeros(3 * n), np.zeros(len(wp))
+    assert host.vigo_host_minsnap(len(wp), wp.ctypes.data_as(_dp), deg, 4, 4, 1.0, None, 0.0, coeffs.ctypes.data_as(_dp),
+                                  knots.ctypes.data_as(_dp)) == 0
+    t = np.array([0.0, 0.3, knots[1] * 0.999, knots[1] + 0.2, knots[2] + 0.05, knots[-1]])
+    out = np.zeros((len(t), 9))
+    assert host.vigo_host_minsnap_eval(len(wp), wp.ctypes.data_as(_dp), deg, 4, 4, 1.0, len(t), t.ctypes.data_as(_dp),
+                                       out.ctypes.data_as(_dp)) == 0
+    c = coeffs.reshape(3, len(wp) - 1, deg + 1)
+    for k, tk in enumerate(t):
+        i = next(j for j in range(len(wp) - 1) if knots[j] <= tk <= knots[j + 1])     # first segment that holds t
+        lt = tk - knots[i]
+        d = np.arange(deg + 1)
+        pos = [sum(c[a, i, q] * lt ** q for q in d) for a in range(3)]
+        vel = [sum(c[a, i, q] * q * lt ** (q - 1) for q in d[1:]) for a in range(3)]
+        acc = [sum(c[a, i, q] * q * (q - 1) * lt ** (q - (1 if a == 0 else 2)) for q in d[2:]) for a in range(3)]
+        assert np.allclose(out[k, 0:3], pos, rtol=1e-12, atol=1e-12)
+        assert np.allclose(out[k, 3:6], vel, rtol=1e-12, atol=1e-12)
+        assert np.allclose(out[k, 6:9], acc, rtol=1e-12, atol=1e-12)
+    # the x component is NOT the second derivative (unless t = 1): the quirk is visible
+    i, lt = 0, 0.3
+    true_ax = sum(c[0, i, q] * q * (q - 1) * lt ** (q - 2) for q in range(2, deg + 1))
+    assert abs(out[1, 6] - true_ax) > 1e-6 * max(1.0, abs(true_ax))

@@ -69,6 +69,8 @@ public:
         return want > 0 && xSol_.size() == want && ySol_.size() == want && zSol_.size() == want;
     }
     pose getPose(double t);
+    Eigen::Vector3d getVel(double t);   /* PS.h:136 */
+    Eigen::Vector3d getAcc(double t);   /* PS.h:137 — the x component with the reference's exponent, see the .cpp */
     void getTrajectory(std::vector<pose>& trajectory, double delT);
     std::vector<double>& getTimeKnot();
     const std::vector<double>& getSolution(int axis) const { return axis == 0 ? xSol_ : (axis == 1 ? ySol_ : zSol_); }

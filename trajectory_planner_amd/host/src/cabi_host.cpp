@@ -83,6 +83,24 @@ int vigo_host_minsnap(int n_wp, const double* wp, int deg, int diff, int cont, d
     return 0;
 }
 
+// the same solve, then polyTrajSolver::getPose / getVel / getAcc at n_t times: out[n_t][9] = position, velocity, acceleration
+int vigo_host_minsnap_eval(int n_wp, const double* wp, int deg, int diff, int cont, double vel, int n_t, const double* t,
+                           double* out) {
+    std::vector<trajPlanner::pose> path;
+    for (int i = 0; i < n_wp; ++i) path.push_back(trajPlanner::pose(wp[3 * i], wp[3 * i + 1], wp[3 * i + 2]));
+    trajPlanner::polyTrajSolver s(deg, diff, cont, vel);
+    s.updatePath(path);
+    if (!s.solve()) return -1;
+    for (int k = 0; k < n_t; ++k) {
+        const trajPlanner::pose p = s.getPose(t[k]);
+        const Eigen::Vector3d v = s.getVel(t[k]), a = s.getAcc(t[k]);
+        double* o = out + 9 * (size_t)k;
+        o[0] = p.x; o[1] = p.y; o[2] = p.z;
+        for (int q = 0; q < 3; ++q) { o[3 + q] = v(q); o[6 + q] = a(q); }
+    }
+    return 0;
+}
+
 // BASELINE configs[0]: one polyTrajOctomap::makePlan() (cfg/planner_interactive.yaml values passed in
 // `cfg`: box[3], map_resolution, sample_delta_time, desired_velocity, initial_radius, shrinking_factor,
 // corridor_res, maximum_iteration_num, traj_timeout, mode) on a dense byte grid (vigo.h voxel

@@ -635,6 +635,49 @@ pose polyTrajSolver::getPose(double t) {
     return p;
 }
 
+// PS.cpp:1080-1100.  (Outside every segment the reference returns an uninitialised vector; here it is zero.)
+Eigen::Vector3d polyTrajSolver::getVel(double t) {
+    Eigen::Vector3d vel(0, 0, 0);
+    if (!hasSolution()) return vel;
+    for (size_t i = 0; i + 1 < desiredTime_.size(); ++i) {
+        if (t >= desiredTime_[i] && t <= desiredTime_[i + 1]) {
+            t = (double)(t - desiredTime_[i]);
+            const int c0 = (polyDegree_ + 1) * (int)i;
+            double vx = 0, vy = 0, vz = 0;
+            for (int d = 1; d < polyDegree_ + 1; ++d) {
+                vx += xSol_[c0 + d] * d * std::pow(t, d - 1);
+                vy += ySol_[c0 + d] * d * std::pow(t, d - 1);
+                vz += zSol_[c0 + d] * d * std::pow(t, d - 1);
+            }
+            vel = Eigen::Vector3d(vx, vy, vz);
+            break;
+        }
+    }
+    return vel;
+}
+
+// PS.cpp:1102-1122 as written: the x component multiplies by pow(t, d-1) where y and z use pow(t, d-2) (:1112) — a caller
+// of the reference gets exactly this, so a drop-in returns it too.
+Eigen::Vector3d polyTrajSolver::getAcc(double t) {
+    Eigen::Vector3d acc(0, 0, 0);
+    if (!hasSolution()) return acc;
+    for (size_t i = 0; i + 1 < desiredTime_.size(); ++i) {
+        if (t >= desiredTime_[i] && t <= desiredTime_[i + 1]) {
+            t = (double)(t - desiredTime_[i]);
+            const int c0 = (polyDegree_ + 1) * (int)i;
+            double ax = 0, ay = 0, az = 0;
+            for (int d = 2; d < polyDegree_ + 1; ++d) {
+                ax += xSol_[c0 + d] * d * (d - 1) * std::pow(t, d - 1);
+                ay += ySol_[c0 + d] * d * (d - 1) * std::pow(t, d - 2);
+                az += zSol_[c0 + d] * d * (d - 1) * std::pow(t, d - 2);
+            }
+            acc = Eigen::Vector3d(ax, ay, az);
+            break;
+        }
+    }
+    return acc;
+}
+
 // PS.cpp:1125-1137
 void polyTrajSolver::getTrajectory(std::vector<pose>& trajectory, double delT) {
     trajectory.clear();
