@@ -25,6 +25,7 @@ def host():
     L.vigo_host_pcd_load.argtypes = [C.c_char_p, C.c_double, _dp, C.c_int, C.c_void_p, C.c_longlong, C.POINTER(C.c_int), _dp,
                                      C.POINTER(C.c_longlong)]
     L.vigo_host_minsnap.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_double, _dp, _dp]
+    L.vigo_host_minsnap_soft.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp]
     L.vigo_host_minsnap_eval.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp]
     return L
 
@@ -364,3 +365,42 @@ def test_polytrajsolver_getvel_getacc_as_the_reference_writes_them(host):
     i, lt = 0, 0.3
     true_ax = sum(c[0, i, q] * q * (q - 1) * lt ** (q - 2) for q in range(2, deg + 1))
     assert abs(out[1, 6] - true_ax) > 1e-6 * max(1.0, abs(true_ax))
+
+
+def test_minsnap_soft_waypoint_constraints(host):
+    """polyTrajSolver::setSoftConstraint (PS.cpp:943-958, bounds :644-659; polyTrajOctomap's yaml soft_constraint /
+    constraint_radius, PO.cpp:98-107, :290-292): the interior waypoints become boxes of half size (rx, ry, rz).  Checked
+    algorithm-independently: KKT conditions with sign-feasible multipliers on the active box sides, feasibility, a cost
+    that can only fall as the boxes grow, and the hard-constraint solution at zero size."""
+    from minsnap_ref import kkt_violation
+    wp = np.array([[0, 0, 1], [2, 0.6, 1], [3, 2.5, 1.2], [5.5, 3, 1], [6.0, 5.0, 1.1]], dtype=float)
+    deg, diff, cont = 7, 4, 4
+    K, D = len(wp) - 1, deg + 1
+    P, A, b, T = minsnap_matrices(wp, deg, diff, cont, 1.0)
+    scale = np.concatenate([(T[s + 1] - T[s]) ** np.arange(D) for s in range(K)])
+    mid = np.arange(2, 2 + K - 1)                       # rows of the interior waypoints (after start and end)
+    rest = np.setdiff1d(np.arange(A.shape[0]), mid)
+    hard, _ = solve_c(host, wp, deg, diff, cont, 1.0)
+    costs = []
+    for soft in ((0.0, 0.0, 0.0), (0.1, 0.1, 0.0), (0.4, 0.4, 0.0), (0.4, 0.2, 0.3)):
+        coeffs, knots = np.zeros((3, K * D)), np.zeros(len(wp))
+        sf = np.array(soft)
+        assert host.vigo_host_minsnap_soft(len(wp), wp.ctypes.data_as(_dp), deg, diff, cont, 1.0, sf.ctypes.data_as(_dp),
+                                           coeffs.ctypes.data_as(_dp), knots.ctypes.data_as(_dp)) == 0
+        total = 0.0
+        for a in range(3):
+            x = coeffs[a] * scale                        # normalised-time coefficients, the QP's variables
+            if soft[a] == 0.0:
+                prim, stat = kkt_violation(P, A, b[:, a], np.zeros((0, K * D)), np.zeros(0), np.zeros(0), x)
+            else:
+                prim, stat = kkt_violation(P, A[rest], b[rest, a], A[mid], b[mid, a] - soft[a], b[mid, a] + soft[a], x, active_tol=1e-6)
+            assert prim < 1e-6 and stat < 1e-6, (soft, a, prim, stat)
+            total += 0.5 * x @ P @ x
+        costs.append(total)
+        if soft == (0.0, 0.0, 0.0):
+            for t in np.linspace(0, T[-1], 50):
+                assert np.allclose(evaluate(coeffs, knots, t), evaluate(hard, knots, t), atol=1e-6)
+        for i in range(1, K):                            # the interior waypoints are met to within the box, z exactly when rz = 0
+            dev = np.abs(evaluate(coeffs, knots, knots[i]) - wp[i])
+            assert np.all(dev <= sf + 1e-6), (soft, i, dev)
+    assert costs[1] < costs[0] and costs[2] < costs[1]   # boxes that contain the previous ones cannot cost more

@@ -160,11 +160,16 @@ public:
                                   Eigen::Vector3d& guidePoint);
     bool hasCollisionTrajectory(const Eigen::MatrixXd& controlPoints);
     bool hasDynamicCollisionTrajectory(const Eigen::MatrixXd& controlPoints);
-
-private:
+    /* public helpers of the reference's class, BT.h:165-172 (its triangle / distance-field / polygon helpers, :173-177,
+       are only called from commented-out code and are not carried) */
+    void shortcutPaths(const std::vector<std::vector<Eigen::Vector3d>>& paths, std::vector<std::vector<Eigen::Vector3d>>& pathsSC);
     bool indexInCollisionSeg(const std::vector<std::pair<int, int>>& collisionSeg, int idx);
+    void compareCollisionSeg(const std::vector<std::pair<int, int>>& prevCollisionSeg, const std::vector<std::pair<int, int>>& newCollisionSeg,
+                             std::vector<int>& newCollisionPoints, std::vector<int>& overlappedCollisionPoints);
     int findCollisionSegIndex(const std::vector<std::pair<int, int>>& collisionSeg, int idx);
     bool isControlPointRequireNewGuide(int controlPointIdx);
+
+private:
     void reboundBegin(Rebound& r);
     /* one pass of the loop body of BT.cpp:619-681 given the gate results; sets r.done/ok/needOptimize */
     void reboundStep(Rebound& r, bool hasCollision, bool hasDynamicCollision, bool timedOut);

@@ -18,6 +18,7 @@
 #include <Eigen/Eigen>
 #include <nav_msgs/Path.h>
 #include <geometry_msgs/PoseStamped.h>
+#include <geometry_msgs/Twist.h>
 #include <map_manager/occupancyMap.h>
 #else
 #include <trajectory_planner/standin/mini_eigen.h>

@@ -30,6 +30,8 @@ private:
     ros::NodeHandle nh_;
     std::vector<double> collisionBox_;  // collision_box, PO.cpp:14-25
     double mapRes_, delT_, desiredVel_, timeout_, initR_, fs_, corridorRes_;
+    bool softConstraint_ = false;             /* PO.cpp:98-107: yaml soft_constraint / constraint_radius */
+    double softConstraintRadius_ = 0.5;
     int polyDegree_, diffDegree_, continuityDegree_, maxIter_;
     bool mode_;                         // true: adding waypoints, false: corridor constraint
     std::vector<pose> path_;
@@ -63,7 +65,9 @@ public:
     void updatePath(const nav_msgs::Path& path);
     void updatePath(const std::vector<pose>& path);
     void updateInitVel(double vx, double vy, double vz);
+    void updateInitVel(const geometry_msgs::Twist& v) { updateInitVel(v.linear.x, v.linear.y, v.linear.z); }   // PO.cpp:202-204
     void updateInitAcc(double ax, double ay, double az);
+    void updateInitAcc(const geometry_msgs::Twist& a) { updateInitAcc(a.linear.x, a.linear.y, a.linear.z); }   // PO.cpp:215-217
     void setDefaultInit();
     /* bypass the QP with a given piecewise polynomial (coefficient blocks per segment, time knots) */
     void setSolution(int polyDegree, const std::vector<double>& xSol, const std::vector<double>& ySol,
@@ -80,6 +84,11 @@ public:
     /* the two planning loops, public in the reference as well (PO.h:100-103) */
     void makePlanAddingWaypoint(std::vector<pose>& trajectory, double delT);
     void makePlanCorridorConstraint(std::vector<pose>& trajectory, double delT);
+    void makePlanAddingWaypoint() { std::vector<pose> t; makePlanAddingWaypoint(t, delT_); }            // PO.cpp:259-322
+    void makePlanCorridorConstraint() { std::vector<pose> t; makePlanCorridorConstraint(t, delT_); }    // PO.cpp:388-452
+    void adjustCorridorSize(const std::set<int>& collisionSeg, std::vector<double>& corridorSizeVec) {   // PO.cpp:188-192
+        for (int s : collisionSeg) corridorSizeVec[s] = corridorSizeVec[s] * fs_;
+    }
     void insertWaypoint(const std::set<int>& seg);                     // PO.cpp:178-186
     /* re-snapshot the map on the next device call (the reference re-fetches /octomap_binary, PO.cpp:133-145) */
     void updateMap() { mapStamp_ = 0; }

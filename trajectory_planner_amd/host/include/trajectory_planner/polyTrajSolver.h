@@ -36,6 +36,8 @@ private:
     double initVel_[3] = {0, 0, 0}, endVel_[3] = {0, 0, 0}, initAcc_[3] = {0, 0, 0}, endAcc_[3] = {0, 0, 0};
     std::vector<double> xSol_, ySol_, zSol_;
     bool corridorConstraint_ = false;
+    bool softConstraint_ = false;            /* PS.cpp:19-22: the interior waypoints as boxes of half size scDeviation_ */
+    double scDeviation_[3] = {0, 0, 0};
     double corridorRes_ = 5.0;
     std::vector<double> corridorSizeVec_;
     std::vector<std::vector<std::pair<double, pose>>> segToTimePose_;  // (normalised time, box centre) per segment
@@ -55,6 +57,9 @@ public:
     void updateEndVel(double vx, double vy, double vz);
     void updateInitAcc(double ax, double ay, double az);
     void updateEndAcc(double ax, double ay, double az);
+    void setSoftConstraint(double r);                              /* PS.cpp:943-958 */
+    void setSoftConstraint(double rx, double ry);
+    void setSoftConstraint(double rx, double ry, double rz);
     void setCorridorConstraint(const std::vector<double>& corridorSizeVec, double corridorRes);
     void setCorridorConstraint(double corridorSize, double corridorRes);
     /* install coefficients computed elsewhere (vigo_minsnap on the device) for the current path;
@@ -69,6 +74,7 @@ public:
         return want > 0 && xSol_.size() == want && ySol_.size() == want && zSol_.size() == want;
     }
     pose getPose(double t);
+    Eigen::Vector3d getPos(double t) { const pose p = getPose(t); return Eigen::Vector3d(p.x, p.y, p.z); }   /* PS.h:135 */
     Eigen::Vector3d getVel(double t);   /* PS.h:136 */
     Eigen::Vector3d getAcc(double t);   /* PS.h:137 — the x component with the reference's exponent, see the .cpp */
     void getTrajectory(std::vector<pose>& trajectory, double delT);

@@ -58,6 +58,8 @@ struct Point { double x = 0, y = 0, z = 0; };
 struct Quaternion { double x = 0, y = 0, z = 0, w = 1; };
 struct Pose { Point position; Quaternion orientation; };
 struct PoseStamped { std_msgs::Header header; Pose pose; };
+struct Vector3 { double x = 0, y = 0, z = 0; };
+struct Twist { Vector3 linear, angular; };
 }  // namespace geometry_msgs
 namespace nav_msgs { struct Path { std_msgs::Header header; std::vector<geometry_msgs::PoseStamped> poses; }; }
 #endif

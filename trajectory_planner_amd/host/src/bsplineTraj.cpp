@@ -507,11 +507,7 @@ bool bsplineTraj::findGuidePointSemiCircle(int controlPointIdx, const std::pair<
 void bsplineTraj::assignGuidePointsSemiCircle(const std::vector<std::vector<Eigen::Vector3d>>& paths,
                                               const std::vector<std::pair<int, int>>& collisionSeg) {
     std::vector<std::vector<Eigen::Vector3d>> pathsSC;
-    for (const auto& p : paths) {
-        std::vector<Eigen::Vector3d> sc;
-        this->shortcutPath(p, sc);
-        pathsSC.push_back(sc);
-    }
+    this->shortcutPaths(paths, pathsSC);
     const int N = this->optData_.controlPoints.cols();
     Eigen::Vector3d guidePoint, guideDirection;
     for (size_t i = 0; i < collisionSeg.size() && i < pathsSC.size(); ++i) {
@@ -564,16 +560,32 @@ bool bsplineTraj::isControlPointRequireNewGuide(int controlPointIdx) {
     return true;
 }
 
-// BT.cpp:573-608 with compareCollisionSeg (BT.h:379-403) inlined
+// BT.h:379-403: the control points of the new collision segments, split into those the previous segments already held
+// and the fresh ones (a segment without interior points contributes both of its ends)
+void bsplineTraj::compareCollisionSeg(const std::vector<std::pair<int, int>>& prevCollisionSeg, const std::vector<std::pair<int, int>>& newCollisionSeg,
+                                      std::vector<int>& newCollisionPoints, std::vector<int>& overlappedCollisionPoints) {
+    for (const auto& s : newCollisionSeg) {
+        for (int i = s.first + 1; i <= s.second - 1; ++i) (indexInCollisionSeg(prevCollisionSeg, i) ? overlappedCollisionPoints : newCollisionPoints).push_back(i);
+        if (s.second - s.first - 1 == 0)
+            for (int i = s.first; i <= s.second; ++i) (indexInCollisionSeg(prevCollisionSeg, i) ? overlappedCollisionPoints : newCollisionPoints).push_back(i);
+    }
+}
+
+// BT.h:249-257
+void bsplineTraj::shortcutPaths(const std::vector<std::vector<Eigen::Vector3d>>& paths, std::vector<std::vector<Eigen::Vector3d>>& pathsSC) {
+    for (const auto& p : paths) {     // (appends: the reference does not clear pathsSC either)
+        std::vector<Eigen::Vector3d> sc;
+        this->shortcutPath(p, sc);
+        pathsSC.push_back(sc);
+    }
+}
+
+// BT.cpp:573-608
 bool bsplineTraj::isReguideRequired(std::vector<std::pair<int, int>>& reguideCollisionSeg) {
     std::vector<std::pair<int, int>> prev = this->collisionSeg_;
     this->findCollisionSeg(this->optData_.controlPoints, this->collisionSeg_);
     std::vector<int> fresh, overlapped;
-    for (const auto& s : this->collisionSeg_) {
-        for (int i = s.first + 1; i <= s.second - 1; ++i) (indexInCollisionSeg(prev, i) ? overlapped : fresh).push_back(i);
-        if (s.second - s.first - 1 == 0)
-            for (int i = s.first; i <= s.second; ++i) (indexInCollisionSeg(prev, i) ? overlapped : fresh).push_back(i);
-    }
+    this->compareCollisionSeg(prev, this->collisionSeg_, fresh, overlapped);
     std::set<int> segIdx;
     for (int i : fresh) segIdx.insert(findCollisionSegIndex(this->collisionSeg_, i));
     for (int i : overlapped)

@@ -83,6 +83,21 @@ int vigo_host_minsnap(int n_wp, const double* wp, int deg, int diff, int cont, d
     return 0;
 }
 
+// min-snap with SOFT interior waypoints (polyTrajSolver::setSoftConstraint, PS.cpp:943-958): soft[3] = half sizes per axis
+int vigo_host_minsnap_soft(int n_wp, const double* wp, int deg, int diff, int cont, double vel, const double* soft,
+                           double* coeffs_out, double* knots_out) {
+    std::vector<trajPlanner::pose> path;
+    for (int i = 0; i < n_wp; ++i) path.push_back(trajPlanner::pose(wp[3 * i], wp[3 * i + 1], wp[3 * i + 2]));
+    trajPlanner::polyTrajSolver s(deg, diff, cont, vel);
+    s.updatePath(path);
+    s.setSoftConstraint(soft[0], soft[1], soft[2]);
+    if (!s.solve()) return -1;
+    const int n = (n_wp - 1) * (deg + 1);
+    for (int a = 0; a < 3; ++a) std::memcpy(coeffs_out + (size_t)a * n, s.getSolution(a).data(), sizeof(double) * n);
+    std::memcpy(knots_out, s.getTimeKnot().data(), sizeof(double) * n_wp);
+    return 0;
+}
+
 // the same solve, then polyTrajSolver::getPose / getVel / getAcc at n_t times: out[n_t][9] = position, velocity, acceleration
 int vigo_host_minsnap_eval(int n_wp, const double* wp, int deg, int diff, int cont, double vel, int n_t, const double* t,
                            double* out) {

@@ -36,6 +36,8 @@ polyTrajOctomap::polyTrajOctomap(const ros::NodeHandle& nh) : nh_(nh) {
     if (!nh_.getParam("initial_radius", initR_)) initR_ = 0.5;
     if (!nh_.getParam("shrinking_factor", fs_)) fs_ = 0.8;
     if (!nh_.getParam("corridor_res", corridorRes_)) corridorRes_ = 5.0;
+    if (!nh_.getParam("soft_constraint", softConstraint_)) softConstraint_ = false;                       // PO.cpp:98-107
+    if (softConstraint_ && !nh_.getParam("constraint_radius", softConstraintRadius_)) softConstraintRadius_ = 0.5;
 }
 
 polyTrajOctomap::~polyTrajOctomap() {
@@ -218,6 +220,7 @@ void polyTrajOctomap::makePlanCorridorConstraint(std::vector<pose>& trajectory, 
     while (!valid) {
         if (nowSec() - t0 >= timeout_) { cout << "[Trajectory Planner INFO]: Timeout." << endl; break; }
         trajSolver_->setCorridorConstraint(corridorSizeVec, corridorRes_);
+        if (softConstraint_) trajSolver_->setSoftConstraint(softConstraintRadius_, softConstraintRadius_, 0);   // PO.cpp:290-292, :354-356, :426-428
         trajSolver_->solve();
         // an infeasible corridor keeps the previous polynomial, like the reference; with none to keep (the very
         // first corridor was infeasible, and shrinking it cannot help) there is nothing to sample: not found
@@ -226,7 +229,7 @@ void polyTrajOctomap::makePlanCorridorConstraint(std::vector<pose>& trajectory, 
         std::set<int> collisionSeg;
         valid = !this->checkCollisionTraj(trajectory, delT, collisionSeg);
         if (!valid)
-            for (int s : collisionSeg) corridorSizeVec[s] *= fs_;   // adjustCorridorSize, PO.cpp:188-192
+            this->adjustCorridorSize(collisionSeg, corridorSizeVec);
         ++countIter;
         if (countIter > maxIter_) break;
     }
@@ -246,6 +249,7 @@ void polyTrajOctomap::makePlanAddingWaypoint(std::vector<pose>& trajectory, doub
     const double t0 = nowSec();
     while (!valid) {
         if (nowSec() - t0 >= timeout_) { cout << "[Trajectory Planner INFO]: Timeout." << endl; break; }
+        if (softConstraint_) trajSolver_->setSoftConstraint(softConstraintRadius_, softConstraintRadius_, 0);   // PO.cpp:290-292, :354-356, :426-428
         trajSolver_->solve();
         if (!trajSolver_->hasSolution()) break;   // degenerate path (e.g. coincident waypoints): nothing to sample
         trajSolver_->getTrajectory(trajectory, delT);
@@ -300,7 +304,8 @@ std::vector<bool> polyTrajOctomap::makePlanBatch(const std::vector<polyTrajOctom
     trajectories.assign(P, {});
     if (P == 0) return result;
     // planners the batch cannot take (installed polynomial, a single waypoint, another polynomial degree, another
-    // map or sweep geometry than the first planner's) plan on their own
+    // map or sweep geometry than the first planner's, soft waypoint constraints — the device QP takes the waypoints
+    // as equalities) plan on their own
     std::vector<size_t> grp;
     for (size_t i = 0; i < P; ++i) {
         polyTrajOctomap* p = ps[i];
@@ -308,7 +313,7 @@ std::vector<bool> polyTrajOctomap::makePlanBatch(const std::vector<polyTrajOctom
         const bool batchable = p->extKnots_.empty() && p->path_.size() >= 2 && p->polyDegree_ == 7 && p->diffDegree_ == ps[0]->diffDegree_ &&
                                p->continuityDegree_ == ps[0]->continuityDegree_ && p->desiredVel_ == ps[0]->desiredVel_ &&
                                p->corridorRes_ == ps[0]->corridorRes_ && p->map_ == ps[0]->map_ && p->collisionBox_ == ps[0]->collisionBox_ &&
-                               p->mapRes_ == ps[0]->mapRes_;
+                               p->mapRes_ == ps[0]->mapRes_ && !p->softConstraint_;
         if (batchable) grp.push_back(i);
         else { p->makePlan(trajectories[i], p->delT_); result[i] = p->findValidTraj_; }
     }

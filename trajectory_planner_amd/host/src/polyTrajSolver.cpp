@@ -444,6 +444,14 @@ void polyTrajSolver::updateEndVel(double vx, double vy, double vz) { endVel_[0] 
 void polyTrajSolver::updateInitAcc(double ax, double ay, double az) { initAcc_[0] = ax; initAcc_[1] = ay; initAcc_[2] = az; }
 void polyTrajSolver::updateEndAcc(double ax, double ay, double az) { endAcc_[0] = ax; endAcc_[1] = ay; endAcc_[2] = az; }
 
+// PS.cpp:943-958
+void polyTrajSolver::setSoftConstraint(double r) { setSoftConstraint(r, r, r); }
+void polyTrajSolver::setSoftConstraint(double rx, double ry) { setSoftConstraint(rx, ry, 0.0); }
+void polyTrajSolver::setSoftConstraint(double rx, double ry, double rz) {
+    softConstraint_ = true;
+    scDeviation_[0] = rx; scDeviation_[1] = ry; scDeviation_[2] = rz;
+}
+
 void polyTrajSolver::setCorridorConstraint(const std::vector<double>& corridorSizeVec, double corridorRes) {
     if (path_.empty()) { std::cout << "[Trajectory Solver]: Invalid! Please load path first!!" << std::endl; return; }
     corridorConstraint_ = true;
@@ -557,7 +565,12 @@ void polyTrajSolver::constructBound(std::vector<double> (&l)[3], std::vector<dou
         eq(row++, s);
         eq(row++, e);
     }
-    for (int i = 0; i < K - 1; ++i) { const double w[3] = {path_[i + 1].x, path_[i + 1].y, path_[i + 1].z}; eq(row++, w); }
+    for (int i = 0; i < K - 1; ++i) {
+        const double w[3] = {path_[i + 1].x, path_[i + 1].y, path_[i + 1].z};
+        if (!softConstraint_) eq(row, w);
+        else for (int a = 0; a < 3; ++a) { l[a][row] = w[a] - scDeviation_[a]; u[a][row] = w[a] + scDeviation_[a]; }   // PS.cpp:644-659
+        ++row;
+    }
     row += K - 1;                               // position continuity: 0
     eq(row++, initVel_); eq(row++, endVel_);
     row += K - 1;

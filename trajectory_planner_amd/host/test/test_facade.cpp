@@ -461,6 +461,38 @@ int main() {
         (void)fresh.makePlan();
         (void)fresh.getPose(0.3);
         std::vector<bsplineTraj*> withNull{&fresh, nullptr};
+        // soft waypoint constraints (yaml soft_constraint / constraint_radius, PO.cpp:98-107): the interior waypoint is a box
+        {
+            ros::NodeHandle nhs;
+            nhs.setParam("collision_box", std::vector<double>{0.4, 0.4, 0.2});
+            nhs.setParam("map_resolution", 0.2);
+            nhs.setParam("sample_delta_time", 0.1);
+            nhs.setParam("traj_timeout", 0.5);
+            nhs.setParam("mode", false);
+            trajPlanner::polyTrajOctomap hardP(nhs);
+            nhs.setParam("soft_constraint", true);
+            nhs.setParam("constraint_radius", 0.3);
+            trajPlanner::polyTrajOctomap softP(nhs);
+            const std::vector<trajPlanner::pose> wps{{-3, 2.2, 1}, {0, 3.4, 1}, {3, 2.2, 1}};     // clear of the pillar
+            std::vector<trajPlanner::pose> th, ts;
+            hardP.setMap(map); hardP.updatePath(wps); hardP.makePlan(th, 0.1);
+            softP.setMap(map); softP.updatePath(wps); softP.makePlan(ts, 0.1);
+            auto nearest = [&](const std::vector<trajPlanner::pose>& t) {
+                double best = 1e9;
+                for (const auto& q : t) best = std::fmin(best, std::hypot(q.x - wps[1].x, q.y - wps[1].y));
+                return best;
+            };
+            std::vector<trajPlanner::polyTrajOctomap*> both{&hardP, &softP};
+            std::vector<std::vector<trajPlanner::pose>> tb;
+            std::vector<bool> rb2 = trajPlanner::polyTrajOctomap::makePlanBatch(both, tb);
+            bool sameSoft = tb.size() == 2 && tb[1].size() == ts.size();
+            for (size_t i = 0; sameSoft && i < ts.size(); ++i) sameSoft = std::fabs(tb[1][i].x - ts[i].x) < 1e-9 && std::fabs(tb[1][i].y - ts[i].y) < 1e-9;
+            std::printf("INFO soft waypoint constraint: hard plan passes the waypoint at %.4f m, soft plan (radius 0.3) at %.4f m\n", nearest(th), nearest(ts));
+            CHECK(hardP.isValid() && softP.isValid() && nearest(th) < 0.06 && nearest(ts) > 0.1 && nearest(ts) < 0.3 * std::sqrt(2.0) + 0.06,
+                  "soft_constraint: the interior waypoint is cut within its box, not interpolated");
+            CHECK(rb2.size() == 2 && rb2[0] && rb2[1] && sameSoft, "makePlanBatch plans a soft-constraint planner on its own, same plan");
+        }
+
         // batch entry points with unprepared planners
         bsplineTraj idle(makeParams());
         std::vector<bsplineTraj*> two{&fresh, &idle};
