@@ -302,7 +302,7 @@ def test_facade_sources_compile_against_the_reference_surface_only(tmp_path):
     import subprocess
     host = os.path.join(ROOT, "trajectory_planner_amd", "host")
     r = subprocess.run(["make", "-C", host, "strict", "-B"], capture_output=True, text=True)
-    assert r.returncode == 0 and "strict: 6 planner sources" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "strict: 7 planner sources" in r.stdout, r.stdout + r.stderr
     bad = tmp_path / "bad.cpp"
     bad.write_text('#include <trajectory_planner/bsplineTraj.h>\n'
                    'unsigned long long f(mapManager::occMap& m) { return m.version + m.voxels().size(); }\n')

@@ -14,6 +14,7 @@
 #define POLYTRAJOCTOMAP_H
 #include <trajectory_planner/compat.h>
 #include <trajectory_planner/mapAdapter.h>
+#include <trajectory_planner/piecewiseLinearTraj.h>
 #include <trajectory_planner/polyTrajSolver.h>
 #include <trajectory_planner/utils.h>
 
@@ -39,7 +40,8 @@ private:
     // an externally supplied piecewise polynomial (setSolution) or the PWL fallback
     int extDegree_ = 0;
     std::vector<double> xSol_, ySol_, zSol_, extKnots_;
-    std::vector<double> pwlKnots_;
+    std::unique_ptr<pwlTraj> pwlTrajSolver_;   // the fallback of PO.cpp:308-318: rotate-then-move along the waypoints
+    std::vector<double> pwlKnots_;             // its time knots (what timeKnots() hands out while it is the plan)
     bool findValidTraj_ = false;
     double initVel_[3] = {0, 0, 0}, initAcc_[3] = {0, 0, 0};
     std::shared_ptr<mapManager::occMap> map_;
@@ -50,7 +52,6 @@ private:
     bool syncDevice();
     bool sweepPoints(const std::vector<pose>& pts, std::vector<uint8_t>& flags);
     void pwlPlan(std::vector<pose>& trajectory, double delT);
-    pose pwlPose(double t);
     pose extPose(double t);
     const std::vector<double>& timeKnots();
 

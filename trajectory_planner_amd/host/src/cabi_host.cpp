@@ -6,6 +6,7 @@
 #endif
 #include <trajectory_planner/octomapBt.h>
 #include <trajectory_planner/path_search/astarOcc.h>
+#include <trajectory_planner/piecewiseLinearTraj.h>
 #include <trajectory_planner/polyTrajOctomap.h>
 #include <trajectory_planner/polyTrajSolver.h>
 
@@ -81,6 +82,27 @@ int vigo_host_minsnap(int n_wp, const double* wp, int deg, int diff, int cont, d
     for (int a = 0; a < 3; ++a) std::memcpy(coeffs_out + (size_t)a * n, s.getSolution(a).data(), sizeof(double) * n);
     std::memcpy(knots_out, s.getTimeKnot().data(), sizeof(double) * n_wp);
     return 0;
+}
+
+// trajPlanner::pwlTraj over n_wp poses (x, y, z, yaw): updatePath(path[, desired_vel], use_yaw), makePlan(traj, delT).
+// desired_vel <= 0: the class default.  traj_out: up to cap poses (x, y, z, yaw); knots_out: up to 2 n_wp doubles.
+// Returns the number of trajectory poses, *n_knots the number of time knots; -2 when traj_out is too small.
+int vigo_host_pwl(int n_wp, const double* wp, int use_yaw, double desired_vel, double delT, double* traj_out, int cap, double* knots_out,
+                  int* n_knots) {
+    std::vector<trajPlanner::pose> path;
+    for (int i = 0; i < n_wp; ++i) path.push_back(trajPlanner::pose(wp[4 * i], wp[4 * i + 1], wp[4 * i + 2], wp[4 * i + 3]));
+    ros::NodeHandle nh;
+    trajPlanner::pwlTraj pw(nh);
+    if (desired_vel > 0) pw.updatePath(path, desired_vel, use_yaw != 0);
+    else pw.updatePath(path, use_yaw != 0);
+    std::vector<trajPlanner::pose> traj;
+    pw.makePlan(traj, delT);
+    const std::vector<double> k = pw.getTimeKnot();
+    *n_knots = (int)k.size();
+    for (size_t i = 0; i < k.size(); ++i) knots_out[i] = k[i];
+    if ((int)traj.size() > cap) return -2;
+    for (size_t i = 0; i < traj.size(); ++i) { traj_out[4 * i] = traj[i].x; traj_out[4 * i + 1] = traj[i].y; traj_out[4 * i + 2] = traj[i].z; traj_out[4 * i + 3] = traj[i].yaw; }
+    return (int)traj.size();
 }
 
 // min-snap with SOFT interior waypoints (polyTrajSolver::setSoftConstraint, PS.cpp:943-958): soft[3] = half sizes per axis

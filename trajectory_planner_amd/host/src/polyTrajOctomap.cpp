@@ -155,29 +155,16 @@ bool polyTrajOctomap::checkCollisionTraj(const std::vector<pose>& trajectory, do
     return has;
 }
 
-// ---- piecewise-linear fallback (role of pwlTraj, piecewiseLinearTraj.cpp:83-121, :163-197): constant
-// speed along the path, yaw along each leg ----
+// ---- the fallback of PO.cpp:308-318, :373-383, :528-541: a fresh pwlTraj over the waypoints (its own 1.0 m/s and
+// 0.5 rad/s, piecewiseLinearTraj.h:20-21 — not the planner's desired velocity), sampled at delT ----
 void polyTrajOctomap::pwlPlan(std::vector<pose>& trajectory, double delT) {
-    pwlKnots_.assign(1, 0.0);
-    for (size_t i = 1; i < path_.size(); ++i) {
-        const double d = std::sqrt(std::pow(path_[i].x - path_[i - 1].x, 2) + std::pow(path_[i].y - path_[i - 1].y, 2) +
-                                   std::pow(path_[i].z - path_[i - 1].z, 2));
-        pwlKnots_.push_back(pwlKnots_.back() + d / desiredVel_);
-    }
+    pwlTrajSolver_.reset(new pwlTraj(nh_));
     trajectory.clear();
-    for (double t = 0; t < pwlKnots_.back(); t += delT) trajectory.push_back(pwlPose(t));
-    trajectory.push_back(path_.back());
-}
-
-pose polyTrajOctomap::pwlPose(double t) {
-    for (size_t i = 0; i + 1 < pwlKnots_.size(); ++i) {
-        if (t >= pwlKnots_[i] && t <= pwlKnots_[i + 1]) {
-            const double a = pwlKnots_[i + 1] > pwlKnots_[i] ? (t - pwlKnots_[i]) / (pwlKnots_[i + 1] - pwlKnots_[i]) : 0.0;
-            const pose &p = path_[i], &q = path_[i + 1];
-            return pose(p.x + (q.x - p.x) * a, p.y + (q.y - p.y) * a, p.z + (q.z - p.z) * a, std::atan2(q.y - p.y, q.x - p.x));
-        }
-    }
-    return path_.empty() ? pose() : path_.back();
+    pwlKnots_.clear();
+    if (path_.empty()) return;
+    pwlTrajSolver_->updatePath(path_);
+    pwlTrajSolver_->makePlan(trajectory, delT);
+    pwlKnots_ = pwlTrajSolver_->getTimeKnot();
 }
 
 // polyTrajSolver::getPose on an externally supplied polynomial (PS.cpp:1026-1056)
@@ -472,7 +459,13 @@ void polyTrajOctomap::trajMsgConverter(const std::vector<pose>& trajectoryTemp, 
 // PO.cpp:658-677
 geometry_msgs::PoseStamped polyTrajOctomap::getPose(double t) {
     if (t > this->getDuration()) t = this->getDuration();
-    pose p = trajSolver_ ? trajSolver_->getPose(t) : (!extKnots_.empty() ? extPose(t) : pwlPose(t));
+    if (!trajSolver_ && extKnots_.empty()) {                     // PO.cpp:672-674: the fallback answers in its own words
+        if (pwlTrajSolver_) return pwlTrajSolver_->getPose(t);
+        geometry_msgs::PoseStamped none;
+        none.header.frame_id = "map";
+        return none;
+    }
+    pose p = trajSolver_ ? trajSolver_->getPose(t) : extPose(t);
     geometry_msgs::PoseStamped ps;
     ps.pose.position.x = p.x; ps.pose.position.y = p.y; ps.pose.position.z = p.z;
     ps.pose.orientation = quaternion_from_rpy(0, 0, p.yaw);
