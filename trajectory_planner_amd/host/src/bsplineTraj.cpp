@@ -571,9 +571,10 @@ void bsplineTraj::compareCollisionSeg(const std::vector<std::pair<int, int>>& pr
     }
 }
 
-// BT.h:249-257
+// BT.h:250-257
 void bsplineTraj::shortcutPaths(const std::vector<std::vector<Eigen::Vector3d>>& paths, std::vector<std::vector<Eigen::Vector3d>>& pathsSC) {
-    for (const auto& p : paths) {     // (appends: the reference does not clear pathsSC either)
+    pathsSC.clear();
+    for (const auto& p : paths) {
         std::vector<Eigen::Vector3d> sc;
         this->shortcutPath(p, sc);
         pathsSC.push_back(sc);
