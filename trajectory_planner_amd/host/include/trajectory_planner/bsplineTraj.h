@@ -142,6 +142,7 @@ public:
     double getDuration();
     double getTimestep();
     Eigen::MatrixXd getControlPoints();
+    const optData& getOptData() const { return optData_; }   /* added (tests): guide points / directions as the optimizer gets them */
     bool isCurrTrajValid();
     bool isCurrTrajValid(Eigen::Vector3d& firstCollisionPos);
     int getLastSolverStatus() const { return lastStatus_; }

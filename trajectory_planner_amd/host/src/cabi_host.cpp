@@ -4,6 +4,7 @@
 #ifdef VIGO_WITH_ROS
 #error "tools of the in-tree dense map (standin/dense_occmap.h): not part of a build against map_manager"
 #endif
+#include <trajectory_planner/bsplineTraj.h>
 #include <trajectory_planner/octomapBt.h>
 #include <trajectory_planner/path_search/astarOcc.h>
 #include <trajectory_planner/piecewiseLinearTraj.h>
@@ -49,6 +50,71 @@ int vigo_host_pcd_load(const char* path, double res, const double* inflate, int 
     if (!out) return 0;
     if ((long long)m->voxels().size() > cap) return -2;
     std::memcpy(out, m->voxels().data(), m->voxels().size());
+    return 0;
+}
+
+// bsplineTraj's host prologue of makePlan() (BT.cpp:333-350: findCollisionSeg -> pathSearch -> assignGuidePointsSemiCircle)
+// on a dense byte grid, after updatePath() over n_path poses (zero start / end conditions).  cfg: distance_threshold,
+// min_height, max_height, max_obstacle_size[3].  Outputs (caller-sized, cap doubles / ints each):
+//   ctrl_out  3 * N control points (column by column), returns N through *n_ctrl
+//   seg_out   pairs of the collision segments AFTER pathSearch, *n_seg of them; -1 in *n_seg when A* failed
+//   guide_off N + 1 offsets into guide_out, which holds (point, direction) 6-tuples per control point, in push order
+//   path_off / path_out: the A* paths (with the segment ends put in, BT.cpp:455-457) as xyz triples
+// Returns 0, -1 when updatePath refuses the path, -2 when a buffer is too small.
+int vigo_host_bspline_prologue(const unsigned char* vox, const int* dims, const double* origin, double res, int n_path, const double* path_xyz,
+                               const double* cfg, double* ctrl_out, int* n_ctrl, int* seg_out, int* n_seg, int* guide_off, double* guide_out,
+                               int* path_off, double* path_out, int cap) {
+    auto m = std::make_shared<mapManager::occMap>(dims[0], dims[1], dims[2], Eigen::Vector3d(origin[0], origin[1], origin[2]), res);
+    std::memcpy(m->voxels().data(), vox, m->voxels().size());
+    ros::NodeHandle nh;
+    nh.setParam("bspline_traj/distance_threshold", cfg[0]);
+    nh.setParam("bspline_traj/min_height", cfg[1]);
+    nh.setParam("bspline_traj/max_height", cfg[2]);
+    nh.setParam("bspline_traj/max_obstacle_size", std::vector<double>{cfg[3], cfg[4], cfg[5]});
+    nh.setParam("bspline_traj/max_path_length", 1000.0);
+    trajPlanner::bsplineTraj bt(nh);
+    bt.setMap(m);
+    nav_msgs::Path path;
+    for (int i = 0; i < n_path; ++i) {
+        geometry_msgs::PoseStamped ps;
+        ps.pose.position.x = path_xyz[3 * i]; ps.pose.position.y = path_xyz[3 * i + 1]; ps.pose.position.z = path_xyz[3 * i + 2];
+        path.poses.push_back(ps);
+    }
+    if (!bt.updatePath(path, std::vector<Eigen::Vector3d>(4, Eigen::Vector3d(0, 0, 0)))) return -1;
+    const Eigen::MatrixXd c = bt.getControlPoints();
+    const int N = (int)c.cols();
+    if (3 * N > cap) return -2;
+    *n_ctrl = N;
+    for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) ctrl_out[3 * i + k] = c(k, i);
+    std::vector<std::pair<int, int>> seg;
+    std::vector<std::vector<Eigen::Vector3d>> paths;
+    bt.findCollisionSeg(c, seg);
+    if (!bt.pathSearch(seg, paths)) { *n_seg = -1; return 0; }
+    bt.assignGuidePointsSemiCircle(paths, seg);
+    if (2 * (int)seg.size() > cap) return -2;
+    *n_seg = (int)seg.size();
+    for (size_t i = 0; i < seg.size(); ++i) { seg_out[2 * i] = seg[i].first; seg_out[2 * i + 1] = seg[i].second; }
+    const trajPlanner::optData& od = bt.getOptData();
+    int g = 0;
+    for (int i = 0; i < N; ++i) {
+        guide_off[i] = g;
+        for (size_t j = 0; j < od.guidePoints[i].size(); ++j) {
+            if (6 * (g + 1) > cap) return -2;
+            for (int k = 0; k < 3; ++k) { guide_out[6 * g + k] = od.guidePoints[i][j](k); guide_out[6 * g + 3 + k] = od.guideDirections[i][j](k); }
+            ++g;
+        }
+    }
+    guide_off[N] = g;
+    int q = 0;
+    for (size_t i = 0; i < paths.size(); ++i) {
+        path_off[i] = q;
+        for (const auto& v : paths[i]) {
+            if (3 * (q + 1) > cap) return -2;
+            for (int k = 0; k < 3; ++k) path_out[3 * q + k] = v(k);
+            ++q;
+        }
+    }
+    path_off[paths.size()] = q;
     return 0;
 }
 
