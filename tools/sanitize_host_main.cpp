@@ -2,10 +2,13 @@
 #include <trajectory_planner/polyTrajSolver.h>
 #include <trajectory_planner/bspline.h>
 #include <trajectory_planner/path_search/astarOcc.h>
+#include <trajectory_planner/piecewiseLinearTraj.h>
 #include <cmath>
 #include <cstdio>
 #include <random>
 #include <string>
+ros::Time ros::Time::now() { return ros::Time(); }   // (the in-tree stand-in's clock lives in bsplineTraj.cpp, which needs HIP)
+
 int main(int argc, char** argv) {
     using namespace trajPlanner;
     int fails = 0;
@@ -96,6 +99,32 @@ int main(int argc, char** argv) {
             (void)a.AstarSearch(0.0, Eigen::Vector3d(0, 0, 1), Eigen::Vector3d(1, 0, 1));                       // zero step
         }
         std::printf("A*: %ld of %ld random queries found a path, %ld broken\n", found, asked, broken);
+    }
+    // pwlTraj (the rotate-then-move fallback) on random paths incl. coincident waypoints, both yaw modes; soft waypoint boxes
+    {
+        ros::NodeHandle nh;
+        for (int k = 0; k < 200; ++k) {
+            const int n = 1 + (int)(5 * std::fabs(U(rng)));
+            std::vector<pose> path;
+            for (int i = 0; i < n; ++i) path.push_back(pose(3 * U(rng), 3 * U(rng), 1 + 0.2 * U(rng), 3.0 * U(rng)));
+            if (k % 7 == 0 && n >= 2) path[1] = path[0];
+            pwlTraj pw(nh);
+            if (k & 1) pw.updatePath(path, k % 3 == 0); else pw.updatePath(path, 0.5 + std::fabs(U(rng)), k % 3 == 0);
+            std::vector<pose> traj;
+            pw.makePlan(traj, 0.1);
+            if (n >= 2 && traj.empty()) ++fails;
+            (void)pw.getPose(-1.0); (void)pw.getPose(0.5 * pw.getDuration()); (void)pw.getPose(1e9); (void)pw.getFirstPose();
+        }
+        for (int k = 0; k < 60; ++k) {
+            const int n = 3 + (int)(4 * std::fabs(U(rng)));
+            std::vector<pose> path;
+            for (int i = 0; i < n; ++i) path.push_back(pose(1.5 * i + 0.4 * U(rng), 1.0 * U(rng), 1.0 + 0.1 * U(rng)));
+            polyTrajSolver sv(7, 4, 4, 1.0);
+            sv.updatePath(path);
+            sv.setSoftConstraint(0.3 * std::fabs(U(rng)), 0.3 * std::fabs(U(rng)), k % 2 ? 0.0 : 0.1);
+            if (!sv.solve()) ++fails;
+            (void)sv.getVel(0.3); (void)sv.getAcc(0.3); (void)sv.getPos(0.3);
+        }
     }
     std::printf("%s\n", fails ? "FAILED" : "sanitizer run complete, no failures");
     return fails;
