@@ -175,6 +175,11 @@ private:
     /* one pass of the loop body of BT.cpp:619-681 given the gate results; sets r.done/ok/needOptimize */
     void reboundStep(Rebound& r, bool hasCollision, bool hasDynamicCollision, bool timedOut);
     bool prepareFitPoints(const nav_msgs::Path& adjustedPath, std::vector<Eigen::Vector3d>& adjustedCurveFitPoints);
+    /* the same with the previous path length (adjustPathLengthDirect's function-static, BT.cpp:755) passed in and out:
+       *wrote says whether the call reached that function at all */
+    bool prepareFitPointsWith(const nav_msgs::Path& adjustedPath, std::vector<Eigen::Vector3d>& adjustedCurveFitPoints, double prevIn,
+                              double& prevOut, bool& wrote);
+    void adjustPathLengthWith(const std::vector<Eigen::Vector3d>& path, std::vector<Eigen::Vector3d>& adjustedPath, double prevIn, double& prevOut);
     void installControlPoints(const Eigen::MatrixXd& controlPoints, const std::vector<Eigen::Vector3d>& adjustedCurveFitPoints);
     bool termCost(int term, const Eigen::MatrixXd& controlPoints, double& cost, Eigen::MatrixXd& gradient);
     void reboundFinish(Rebound& r, bool ok);

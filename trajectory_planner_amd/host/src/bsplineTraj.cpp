@@ -51,6 +51,16 @@ ros::Time ros::Time::now() {
 
 namespace trajPlanner {
 
+// The reference keeps the length of the previous call's path in a function-static shared by all instances (BT.cpp:755):
+// kept here as one process-wide value, read and written through adjustPathLengthWith so that updatePathBatch can run
+// the planners' prologues on several host threads and still hand every planner the value its predecessor left.
+// (atomic only so that two host threads planning two batches do not race on it formally; WHICH value a planner of one
+// batch sees when another batch runs at the same time is as unspecified as it is for the reference's static)
+namespace {
+std::atomic<double> g_prevPathLength{0.0};
+}
+
+
 bsplineTraj::bsplineTraj() {}
 
 bsplineTraj::bsplineTraj(const ros::NodeHandle& nh) : nh_(nh) { this->initParam(); }
@@ -223,6 +233,19 @@ bool bsplineTraj::fillPath(const nav_msgs::Path& path, nav_msgs::Path& adjustedP
 // BT.cpp:290-312: everything of updatePath() before the fit — goal check, path-length adjustment,
 // filling short paths, clear() — leaving the curve-fit points
 bool bsplineTraj::prepareFitPoints(const nav_msgs::Path& adjustedPath, std::vector<Eigen::Vector3d>& adjustedCurveFitPoints) {
+    bool wrote = false;
+    const double prevIn = g_prevPathLength.load();
+    double prevOut = prevIn;
+    const bool ok = this->prepareFitPointsWith(adjustedPath, adjustedCurveFitPoints, prevIn, prevOut, wrote);
+    if (wrote) g_prevPathLength.store(prevOut);
+    return ok;
+}
+
+bool bsplineTraj::prepareFitPointsWith(const nav_msgs::Path& adjustedPath, std::vector<Eigen::Vector3d>& adjustedCurveFitPoints, double prevIn,
+                                       double& prevOut, bool& wrote) {
+    wrote = false;
+    prevOut = prevIn;
+    adjustedCurveFitPoints.clear();
     if (adjustedPath.poses.empty() || !map_) return false;
     Eigen::Vector3d goal(adjustedPath.poses.back().pose.position.x, adjustedPath.poses.back().pose.position.y,
                          adjustedPath.poses.back().pose.position.z);
@@ -232,7 +255,8 @@ bool bsplineTraj::prepareFitPoints(const nav_msgs::Path& adjustedPath, std::vect
     }
     std::vector<Eigen::Vector3d> adjustedPathVec, inputPathVec;
     this->pathMsgToEigenPoints(adjustedPath, adjustedPathVec);
-    this->adjustPathLengthDirect(adjustedPathVec, inputPathVec);
+    this->adjustPathLengthWith(adjustedPathVec, inputPathVec, prevIn, prevOut);
+    wrote = true;
     nav_msgs::Path inputPath;
     this->eigenPointsToPathMsg(inputPathVec, inputPath);
     if (inputPath.poses.size() < 4) {
@@ -276,8 +300,28 @@ std::vector<bool> bsplineTraj::updatePathBatch(const std::vector<bsplineTraj*>& 
     if (paths.size() != planners.size() || startEndConditions.size() != planners.size()) return ok;
     std::vector<std::vector<Eigen::Vector3d>> fitPts(planners.size());
     std::vector<bool> ready(planners.size(), false);
-    for (size_t i = 0; i < planners.size(); ++i)
-        ready[i] = startEndConditions[i].size() == 4 && planners[i]->prepareFitPoints(paths[i], fitPts[i]) && fitPts[i].size() > 3;
+    // The prologues (goal check, path-length adjustment with its line checks against the map, filling) run on the host
+    // workers, each as if its predecessor had left a previous path length not above its own max_path_length — then the
+    // value does not enter (BT.cpp:762: max(prevPathLength, maxPathLength_)); a serial pass hands the real value down the
+    // line and repeats, in order, the rare planner for which it does enter.  Same results as one planner after another.
+    std::vector<uint8_t> okv(planners.size(), 0), wrote(planners.size(), 0);
+    std::vector<double> prevOut(planners.size(), 0.0);
+    parallelFor(planners.size(), [&](size_t i) {
+        if (startEndConditions[i].size() != 4) return;
+        bool w = false;
+        okv[i] = planners[i]->prepareFitPointsWith(paths[i], fitPts[i], 0.0, prevOut[i], w) ? 1 : 0;
+        wrote[i] = w ? 1 : 0;
+    });
+    double prev = g_prevPathLength.load();
+    for (size_t i = 0; i < planners.size(); ++i) {
+        if (startEndConditions[i].size() == 4 && wrote[i] && prev > planners[i]->maxPathLength_) {
+            bool w = false;
+            okv[i] = planners[i]->prepareFitPointsWith(paths[i], fitPts[i], prev, prevOut[i], w) ? 1 : 0;
+        }
+        if (wrote[i]) prev = prevOut[i];
+        ready[i] = okv[i] && fitPts[i].size() > 3;
+    }
+    g_prevPathLength.store(prev);
     std::vector<bool> doneMask(planners.size(), false);
     for (size_t a = 0; a < planners.size(); ++a) {
         if (doneMask[a] || !ready[a]) continue;
@@ -303,13 +347,13 @@ std::vector<bool> bsplineTraj::updatePathBatch(const std::vector<bsplineTraj*>& 
             continue;
         }
         if (!vigo_host::threadSync() || !dCtrl.download(ctrl.data(), ctrl.size() * 8)) continue;
-        for (int b = 0; b < B; ++b) {
+        parallelFor((size_t)B, [&](size_t b) {
             Eigen::MatrixXd controlPoints;
             controlPoints.resize(3, K + 2);
-            std::memcpy(controlPoints.data(), ctrl.data() + (size_t)b * (K + 2) * 3, sizeof(double) * 3 * (K + 2));
+            std::memcpy(controlPoints.data(), ctrl.data() + b * (K + 2) * 3, sizeof(double) * 3 * (K + 2));
             planners[grp[b]]->installControlPoints(controlPoints, fitPts[grp[b]]);
-            ok[grp[b]] = true;
-        }
+        });
+        for (int b = 0; b < B; ++b) ok[grp[b]] = true;
     }
     return ok;
 }
@@ -1212,7 +1256,15 @@ std::vector<bool> bsplineTraj::makePlanBatch(const std::vector<bsplineTraj*>& pl
 
 // BT.cpp:754-793 — including the function-static previous goal distance shared by all instances
 void bsplineTraj::adjustPathLengthDirect(const std::vector<Eigen::Vector3d>& path, std::vector<Eigen::Vector3d>& adjustedPath) {
-    static double prevPathLength = 0.0;
+    double prevOut = 0.0;
+    this->adjustPathLengthWith(path, adjustedPath, g_prevPathLength.load(), prevOut);
+    g_prevPathLength.store(prevOut);
+}
+
+void bsplineTraj::adjustPathLengthWith(const std::vector<Eigen::Vector3d>& path, std::vector<Eigen::Vector3d>& adjustedPath, double prevIn,
+                                       double& prevOut) {
+    const double prevPathLength = prevIn;
+    prevOut = prevIn;
     if (path.empty()) return;
     double totalLength = 0.0;
     bool exceedLength = false;
@@ -1227,7 +1279,7 @@ void bsplineTraj::adjustPathLengthDirect(const std::vector<Eigen::Vector3d>& pat
             bool free = !this->map_->isInflatedOccupiedLine(p1, p2);
             if (free && minLength >= 1.5) {
                 adjustedPath.push_back(p2);
-                prevPathLength = totalLength;
+                prevOut = totalLength;
                 return;
             }
         }
@@ -1235,7 +1287,7 @@ void bsplineTraj::adjustPathLengthDirect(const std::vector<Eigen::Vector3d>& pat
         else minLength += (p2 - p1).norm();
     }
     adjustedPath.push_back(path.back());
-    prevPathLength = totalLength;
+    prevOut = totalLength;
 }
 
 // BT.cpp:1116-1137

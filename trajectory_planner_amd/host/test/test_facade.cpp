@@ -319,6 +319,56 @@ int main() {
         CHECK(same == (int)ps.size(), "a batch of planners with different parameters and maps == each planned alone");
     }
 
+    // ---- updatePathBatch runs the planners' prologues on the host workers; the previous path length that
+    //      adjustPathLengthDirect hands from one call to the next (the reference's function-static, BT.cpp:755) must
+    //      still go down the line in order: paths longer than max_path_length (7 m) make it matter ----
+    {
+        auto mk = [&]() {
+            ros::NodeHandle nh = makeParams();
+            nh.setParam("bspline_traj/max_path_length", 7.0);      // the reference's default, BT.cpp:152
+            std::unique_ptr<bsplineTraj> q(new bsplineTraj(nh));
+            q->setMap(map);
+            q->updateMaxVel(2.0);
+            q->updateMaxAcc(3.0);
+            return q;
+        };
+        std::vector<nav_msgs::Path> paths;
+        for (int i = 0; i < 40; ++i) {
+            const double y = 2.0 + 0.08 * i;                       // clear of the pillar
+            const double x1 = (i % 5 == 2) ? 5.5 : ((i % 7 == 3) ? 4.9 : 2.0 + 0.05 * i);   // 11.5 m, 10.9 m, or 5 .. 7 m long
+            paths.push_back(straight(-6.0, y, x1, y + 0.05, 1.0, 0.25));
+        }
+        const nav_msgs::Path reset = straight(-3.0, 3.0, 0.0, 3.0, 1.0, 0.25);   // leaves the shared value at 3 m
+        std::vector<std::unique_ptr<bsplineTraj>> seqO, batO;
+        std::vector<bsplineTraj*> bat;
+        for (int i = 0; i < 40; ++i) { seqO.push_back(mk()); batO.push_back(mk()); bat.push_back(batO.back().get()); }
+        auto dummy = mk();
+        dummy->updatePath(reset, cond);
+        std::vector<bool> us(40);
+        for (int i = 0; i < 40; ++i) us[i] = seqO[i]->updatePath(paths[i], cond);
+        dummy->updatePath(reset, cond);
+        std::vector<bool> ub = bsplineTraj::updatePathBatch(bat, paths, std::vector<std::vector<Eigen::Vector3d>>(40, cond));
+        int same = 0, shortened = 0;
+        for (int i = 0; i < 40; ++i) {
+            const Eigen::MatrixXd a = seqO[i]->getControlPoints(), b = batO[i]->getControlPoints();
+            double worst = 0;
+            for (int c = 0; c < a.cols() && c < b.cols(); ++c) for (int k = 0; k < 3; ++k) worst = std::fmax(worst, std::fabs(a(k, c) - b(k, c)));
+            same += (bool)us[i] == (bool)ub[i] && a.cols() == b.cols() && worst < 1e-9;
+            shortened += a.cols() < (int)paths[i].poses.size() + 2;
+        }
+        // and the value left behind is the same: one more planner after each run
+        auto tailS = mk(), tailB = mk();
+        dummy->updatePath(reset, cond);
+        for (int i = 0; i < 40; ++i) seqO[i]->updatePath(paths[i], cond);
+        tailS->updatePath(paths[2], cond);
+        dummy->updatePath(reset, cond);
+        bsplineTraj::updatePathBatch(bat, paths, std::vector<std::vector<Eigen::Vector3d>>(40, cond));
+        tailB->updatePath(paths[2], cond);
+        std::printf("INFO updatePathBatch vs one planner after another: %d of 40 equal, %d paths shortened by the length rule\n", same, shortened);
+        CHECK(same == 40 && shortened > 0 && tailS->getControlPoints().cols() == tailB->getControlPoints().cols(),
+              "updatePathBatch (prologues on the host workers) == updatePath one planner after another, previous path length handed down in order");
+    }
+
     // ---- polyTrajOctomap checker ----
     {
         ros::NodeHandle nh;
