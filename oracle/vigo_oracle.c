@@ -941,12 +941,19 @@ int vgo_sample_times(double tmax, double dt, double* times, int cap) {
 }
 
 /* BT.h:307-325 */
+static int traj_collision_ncr(const vgo_grid_t* g, int N, const double* ctrl, double ts_ctrl, double dt,
+                              double not_check_ratio, int* first_idx);
 int vgo_traj_collision(const vgo_grid_t* g, int N, const double* ctrl, double ts_ctrl, double dt,
                        int* first_idx) {
+    return traj_collision_ncr(g, N, ctrl, ts_ctrl, dt, 0.0, first_idx);   /* notCheckRatio_ = 0.0, BT.h:58 */
+}
+/* BT.h:307-325 with notCheckRatio_ as a parameter (BT.h:313) */
+static int traj_collision_ncr(const vgo_grid_t* g, int N, const double* ctrl, double ts_ctrl, double dt,
+                              double not_check_ratio, int* first_idx) {
     double duration = (N - 3) * ts_ctrl; /* knots(N) BS.cpp:27 */
     int k = 0;
     if (first_idx) *first_idx = -1;
-    for (double t = 0; t <= (1.0 - 0.0) * duration; t += dt, ++k) {
+    for (double t = 0; t <= (1.0 - not_check_ratio) * duration; t += dt, ++k) {
         double p[3];
         vgo_bspline_at(3, N, ctrl, ts_ctrl, t, p);
         if (vgo_is_inflated_occupied(g, p)) {
@@ -1071,7 +1078,7 @@ int vgo_is_reguide_required(const vigo_params_t* P, const vgo_grid_t* g, int N, 
 int vgo_rebound_decide(const vigo_params_t* P, const vgo_grid_t* g, int N, const double* ctrl, const int32_t* goff,
                        const double* gpv, int n_obs, const double* obs, double gate_dt, double not_check_ratio,
                        double* weights, vigo_rebound_state_t* st) {
-    int hasCollision = vgo_traj_collision(g, N, ctrl, P->ts_ctrl, gate_dt, NULL);
+    int hasCollision = traj_collision_ncr(g, N, ctrl, P->ts_ctrl, gate_dt, not_check_ratio, NULL);
     int hasDynamicCollision = n_obs > 0 ? vgo_traj_dynamic_collision(N, ctrl, P->ts_ctrl, gate_dt, n_obs, obs) : 0;
     st->gate_static = hasCollision;
     st->gate_dynamic = hasDynamicCollision;

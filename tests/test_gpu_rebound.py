@@ -64,8 +64,11 @@ def oracle_rounds(P, world, b, weights, state, gate_dt, max_rounds, ncr=0.0):
     return ctrl, w, st
 
 
-@pytest.mark.parametrize("N,B,n_obs,fail0,rounds", [(32, 96, 0, 0, 1), (32, 200, 2, 0, 4), (20, 64, 1, 3, 3), (64, 40, 0, 2, 2), (100, 12, 1, 0, 2)])
-def test_rebound_rounds_match_the_oracle(small_world, N, B, n_obs, fail0, rounds):
+# (ncr = notCheckRatio_, BT.h:58 — 0.0 in the reference; a non-zero value shortens the static gate, BT.h:313, and the
+# range findCollisionSeg walks, BT.cpp:406, but not the dynamic gate, BT.h:345)
+@pytest.mark.parametrize("N,B,n_obs,fail0,rounds,ncr", [(32, 96, 0, 0, 1, 0.0), (32, 200, 2, 0, 4, 0.0), (20, 64, 1, 3, 3, 0.0), (64, 40, 0, 2, 2, 0.0),
+                                                         (100, 12, 1, 0, 2, 0.0), (32, 160, 1, 1, 3, 1.0 / 3.0), (48, 64, 0, 0, 2, 0.6)])
+def test_rebound_rounds_match_the_oracle(small_world, N, B, n_obs, fail0, rounds, ncr):
     P = default_params()
     P.max_iterations = 40
     v = Vigo(0, P)
@@ -83,7 +86,7 @@ def test_rebound_rounds_match_the_oracle(small_world, N, B, n_obs, fail0, rounds
     g, keep = ol.make_grid(small_world)
     for i in range(B):
         seg = np.zeros(2 * Vigo.REBOUND_MAX_SEGS, dtype=np.int32)
-        n = ol.oracle().vgo_find_collision_seg(C.byref(g), N, ol._d(np.ascontiguousarray(b.ctrl[i])), 0.0, ol._i(seg), Vigo.REBOUND_MAX_SEGS)
+        n = ol.oracle().vgo_find_collision_seg(C.byref(g), N, ol._d(np.ascontiguousarray(b.ctrl[i])), ncr, ol._i(seg), Vigo.REBOUND_MAX_SEGS)
         state[i, S_NSEG] = n
         state[i, S_SEG:] = seg
     gate_dt = small_world.res / 1.0 / 2.0
@@ -91,53 +94,94 @@ def test_rebound_rounds_match_the_oracle(small_world, N, B, n_obs, fail0, rounds
     d_w, d_state = to_dev(weights, v.device), to_dev(state, v.device)
     gunk = v.guides_unknown(d["guide_pv"]) if len(b.guide_pv) else None
     v.rebound_rounds(d["ctrl"], d["guide_off"], d["guide_pv"] if len(b.guide_pv) else None, gunk, d["obs_off"], d["obs"], d_w, gate_dt, d_state,
-                     max_rounds=rounds)
+                     max_rounds=rounds, not_check_ratio=ncr)
     torch.cuda.synchronize()
-    ctrl_ref, w_ref, st_ref = oracle_rounds(P, small_world, b, weights, state, gate_dt, rounds)
+    ctrl_ref, w_ref, st_ref = oracle_rounds(P, small_world, b, weights, state, gate_dt, rounds, ncr)
     st = d_state.cpu().numpy()
     assert np.array_equal(st, st_ref), np.argwhere(st != st_ref)[:10]
     assert np.array_equal(d_w.cpu().numpy(), w_ref)
     assert np.array_equal(d["ctrl"].cpu().numpy(), ctrl_ref)
     kinds = set(np.unique(st[:, S_STATUS]))
-    print(f"\\n[N={N} B={B} obs={n_obs}] after {rounds} round(s): done {(st[:, 0] == 1).sum()}, needs A* {(st[:, 0] == 2).sum()}, "
+    print(f"\n[N={N} B={B} obs={n_obs} ncr={ncr:.2f}] after {rounds} round(s): done {(st[:, 0] == 1).sum()}, needs A* {(st[:, 0] == 2).sum()}, "
           f"active {(st[:, 0] == 0).sum()} (deferred solves {(st[:, S_SOLVE] != 0).sum()}), max failCount {st[:, S_FAIL].max()}")
     assert Vigo.RB_DONE in kinds
     v.close()
 
 
-def test_rebound_rounds_stay_on_the_device_while_nobody_needs_a_star(small_world):
-    """every control point keeps a guide pair that still pulls (dthresh - dist > 0) and the previous collision segment
-    covers the whole trajectory: isReguideRequired is false in the first round, so the colliding trajectories double
-    their weight and re-solve on the device, and the batch goes on to a second resident round (where the narrower
-    segments the first round recorded make a few trajectories ask for A*, which ends the call for everyone)"""
-    P = default_params()
-    P.max_iterations = 25
-    v = Vigo(0, P)
-    v.set_grid(to_dev(small_world.voxels, v.device), small_world.origin, small_world.res)
-    B, N = 128, 32
-    b0 = synth.make_bspline_batch(small_world, B, N, 4711, start_range=3.5, n_obs=1)
+def _pulling_guides_everywhere(world, B, N, seed, w_distance, P):
+    """every control point (the fixed end points too: a collision segment may name them) gets ONE guide pair whose point
+    lies 3 m ahead in a random horizontal direction, so dthresh - dist = 3.5 > 0 for good ("still can be adjusted by
+    increasing distance weight", BT.h:424-426): isControlPointRequireNewGuide is false for every point, always; the
+    previous collision segment covers the whole trajectory, so no colliding point of the first round is new."""
+    b0 = synth.make_bspline_batch(world, B, N, seed, start_range=3.5, n_obs=0)
     rng = np.random.default_rng(5)
-    counts = np.ones((B, N), dtype=np.int32)      # (the fixed end points too: a collision segment may name them)
-    goff = np.zeros(B * N + 1, dtype=np.int32)
-    goff[1:] = np.cumsum(counts.reshape(-1))
+    goff = np.arange(B * N + 1, dtype=np.int32)
     c = b0.ctrl.reshape(-1, 3)
     u = rng.normal(size=c.shape)
     u[:, 2] = 0.0
     u /= np.linalg.norm(u, axis=1, keepdims=True)
-    gpv = np.ascontiguousarray(np.concatenate([c + 3.0 * u, u], axis=1))     # guide points far ahead: never reached
-    b = synth.Batch(b0.ctrl, goff, gpv, synth.lookup(small_world, gpv[:, :3], 1).astype(np.uint8), b0.obs_off, b0.obs)
-    # a distance weight too small to push any control point past its guide's threshold: "the weight is not big enough"
-    weights = np.tile(np.array([1e-4, P.w_smoothness, P.w_feasibility, P.w_dynamic]), (B, 1))
+    gpv = np.ascontiguousarray(np.concatenate([c + 3.0 * u, u], axis=1))
+    b = synth.Batch(b0.ctrl, goff, gpv, synth.lookup(world, gpv[:, :3], 1).astype(np.uint8), None, None)
+    weights = np.tile(np.array([w_distance, P.w_smoothness, P.w_feasibility, P.w_dynamic]), (B, 1))
     state = np.zeros((B, Vigo.REBOUND_STATE_INTS), dtype=np.int32)
     state[:, S_SOLVE] = 1
     state[:, S_NSEG] = 1
     state[:, S_SEG] = 2
     state[:, S_SEG + 1] = N - 1
+    return b, weights, state
+
+
+def test_four_doublings_on_the_device_then_the_hand_over_at_fail_count_4(small_world):
+    """BT.cpp:640-648, :667-673 from the decision rule, not from luck.  A distance weight of 1e-7 cannot move a control
+    point however often it doubles, so: the owed optimize() converges on smoothness + feasibility alone (status 0);
+    round 1 finds the collision, nobody needs a new guide (see _pulling_guides_everywhere), the weight doubles and the
+    re-solve ends at once (gradient norm already under g_epsilon: status 2, control points untouched); rounds 2 - 4 find
+    the SAME collision segments (no new colliding point) and double again; round 5 sees failCount == 4 and hands the
+    trajectory to the host's A*.  Every colliding trajectory: rounds == 5, failCount == 4, weight x 16, NEEDS_HOST,
+    four doublings without a host round trip — and everything equal to the oracle's replay."""
+    P = default_params()
+    P.max_iterations = 200                       # the reference's cap (BT.cpp:698): the first solve converges
+    v = Vigo(0, P)
+    v.set_grid(to_dev(small_world.voxels, v.device), small_world.origin, small_world.res)
+    B, N, w0 = 128, 32, 1e-7
+    b, weights, state = _pulling_guides_everywhere(small_world, B, N, 4711, w0, P)
     gate_dt = 0.05
     d = batch_to_dev(b, v.device)
     d_w, d_state = to_dev(weights, v.device), to_dev(state, v.device)
     gunk = v.guides_unknown(d["guide_pv"])
-    v.rebound_rounds(d["ctrl"], d["guide_off"], d["guide_pv"], gunk, d["obs_off"], d["obs"], d_w, gate_dt, d_state, max_rounds=6)
+    v.rebound_rounds(d["ctrl"], d["guide_off"], d["guide_pv"], gunk, None, None, d_w, gate_dt, d_state, max_rounds=6)
+    torch.cuda.synchronize()
+    ctrl_ref, w_ref, st_ref = oracle_rounds(P, small_world, b, weights, state, gate_dt, 6)
+    st, w = d_state.cpu().numpy(), d_w.cpu().numpy()
+    assert np.array_equal(st, st_ref) and np.array_equal(w, w_ref) and np.array_equal(d["ctrl"].cpu().numpy(), ctrl_ref)
+    host = st[:, S_STATUS] == Vigo.RB_NEEDS_HOST
+    done = st[:, S_STATUS] == Vigo.RB_DONE
+    print(f"\nfour doublings: handed to A* {host.sum()}, collision free after the first solve {done.sum()}, "
+          f"rounds {np.bincount(st[:, S_ROUNDS])}, failCount {np.bincount(st[:, S_FAIL])}")
+    assert host.sum() > B // 2 and host.sum() + done.sum() == B
+    assert np.all(st[host, S_ROUNDS] == 5) and np.all(st[host, S_FAIL] == 4) and np.all(st[host, S_GSTAT] == 1)
+    assert np.array_equal(w[host, 0], np.full(host.sum(), w0 * 16.0)) and np.array_equal(w[host, 1:], weights[host, 1:])
+    assert np.all(st[host, S_LBFGS] == 2)        # LBFGS_ALREADY_MINIMIZED: the last re-solve had nothing to do
+    assert np.all(st[done, S_ROUNDS] == 1) and np.all(st[done, S_FAIL] == 0) and np.array_equal(w[done], weights[done])
+    v.close()
+
+
+def test_rebound_rounds_stay_on_the_device_while_nobody_needs_a_star(small_world):
+    """the same construction with a weight that does move the trajectory a little (1e-4) and a 25-iteration cap: the
+    first round doubles on the device, the batch goes on to a second resident round, where the narrower segments the
+    first round recorded make a few trajectories ask for A* (a colliding point outside them is new, BT.cpp:583-588),
+    which ends the call for everyone"""
+    P = default_params()
+    P.max_iterations = 25
+    v = Vigo(0, P)
+    v.set_grid(to_dev(small_world.voxels, v.device), small_world.origin, small_world.res)
+    B, N = 128, 32
+    b, weights, state = _pulling_guides_everywhere(small_world, B, N, 4711, 1e-4, P)
+    gate_dt = 0.05
+    d = batch_to_dev(b, v.device)
+    d_w, d_state = to_dev(weights, v.device), to_dev(state, v.device)
+    gunk = v.guides_unknown(d["guide_pv"])
+    v.rebound_rounds(d["ctrl"], d["guide_off"], d["guide_pv"], gunk, None, None, d_w, gate_dt, d_state, max_rounds=6)
     torch.cuda.synchronize()
     ctrl_ref, w_ref, st_ref = oracle_rounds(P, small_world, b, weights, state, gate_dt, 6)
     st = d_state.cpu().numpy()

@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <numeric>
+#include <stdexcept>
 
 int main() {
     std::atomic<long> bad{0};
@@ -23,6 +24,33 @@ int main() {
     for (int t = 0; t < 4; ++t) callers.emplace_back(caller, t);
     caller(99);   // and the main thread
     for (auto& t : callers) t.join();
-    std::printf("%s\n", bad.load() ? "FAILED" : "worker pool: 1500 parallelFor calls from 5 caller threads, all sums right");
+    // a parallelFor nested on the calling thread (same pool: must run serially, not overwrite the job in flight) and on
+    // the workers (their own pools)
+    {
+        const size_t n = 400, m = 64;
+        std::vector<std::atomic<int>> hits(n * m);
+        for (auto& h : hits) h.store(0);
+        vigo_host::parallelFor(n, [&](size_t i) { vigo_host::parallelFor(m, [&](size_t j) { hits[i * m + j].fetch_add(1); }); });
+        for (auto& h : hits) if (h.load() != 1) ++bad;
+    }
+    // fn throws, on whichever thread draws index 137: every other thread has left the job before run() unwinds, the
+    // exception arrives on the caller, and the pool is usable afterwards
+    for (int rep = 0; rep < 50; ++rep) {
+        std::atomic<int> ran{0};
+        bool caught = false;
+        try {
+            vigo_host::parallelFor(600, [&](size_t i) {
+                if (i == 137) throw std::runtime_error("boom");
+                ran.fetch_add(1);
+            });
+        } catch (const std::runtime_error&) {
+            caught = true;
+        }
+        if (!caught || ran.load() >= 600) ++bad;
+        std::vector<int> out(300, 0);
+        vigo_host::parallelFor(out.size(), [&](size_t i) { out[i] = 1; });
+        if (std::accumulate(out.begin(), out.end(), 0) != 300) ++bad;
+    }
+    std::printf("%s\n", bad.load() ? "FAILED" : "worker pool: 1500 parallelFor calls from 5 caller threads, all sums right; nested and throwing jobs handled");
     return bad.load() != 0;
 }

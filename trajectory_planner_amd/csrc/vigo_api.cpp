@@ -68,6 +68,20 @@ int check_list_args(vigo_handle_t h, const void* guide_off, const void* guide_pv
 // accumulation, reproduced exactly by vigo::accumulated_time (closed form per binade).  The sample count T is
 // found on the host by bisection over that closed form (monotone in k), the table is filled by a device kernel
 // and cached in the handle per (dt, tmax): the gates run without a host round trip.
+// number of samples of `for (t = 0; t <= tmax; t += dt)` (the accumulated clock, exactly): bisection over the closed form,
+// monotone in k.  -1: more than 2^24 samples.
+static int count_sample_times(double dt, double tmax) {
+    if (!(tmax >= 0.0)) return 0;
+    const int64_t cap = (int64_t)1 << 24;
+    if (vigo::accumulated_time(dt, cap) <= tmax) return -1;
+    int64_t lo = 0, hi = cap;                       // t_lo <= tmax < t_hi
+    while (hi - lo > 1) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (vigo::accumulated_time(dt, mid) <= tmax) lo = mid; else hi = mid;
+    }
+    return (int)hi;                                 // samples k = 0 .. lo
+}
+
 int upload_sample_times(vigo_handle_t h, double tmax, double dt, int* out_T, const double** out_dev) {
     if (!(dt > 0.0)) return fail(h, VIGO_ERR_INVALID_ARG, "dt must be > 0");
     if (h->times_T >= 0 && h->times_dt == dt && h->times_tmax == tmax) {
@@ -79,17 +93,8 @@ int upload_sample_times(vigo_handle_t h, double tmax, double dt, int* out_T, con
         *out_dev = h->times_dev;
         return VIGO_OK;
     }
-    int T = 0;
-    if (tmax >= 0.0) {
-        const int64_t cap = (int64_t)1 << 24;
-        if (vigo::accumulated_time(dt, cap) <= tmax) return fail(h, VIGO_ERR_INVALID_ARG, "too many samples");
-        int64_t lo = 0, hi = cap;                       // t_lo <= tmax < t_hi
-        while (hi - lo > 1) {
-            const int64_t mid = lo + (hi - lo) / 2;
-            if (vigo::accumulated_time(dt, mid) <= tmax) lo = mid; else hi = mid;
-        }
-        T = (int)hi;                                    // samples k = 0 .. lo
-    }
+    const int T = count_sample_times(dt, tmax);
+    if (T < 0) return fail(h, VIGO_ERR_INVALID_ARG, "too many samples");
     if ((size_t)T > h->times_cap) {
         if (h->times_dev) (void)hipFree(h->times_dev);
         h->times_dev = nullptr;
@@ -503,6 +508,10 @@ int vigo_rebound_rounds(vigo_handle_t h, int B, int N, double* ctrl, const int32
     r.obs_off = obs_off; r.obs = obs; r.n_obs_shared = n_obs_shared;
     r.weights = weights; r.state = state;
     r.ts_ctrl = h->params.ts_ctrl; r.T = T; r.times = times;
+    // the static gate stops at (1 - notCheckRatio_) * duration (BT.h:313); the dynamic one samples the whole
+    // trajectory (evalTraj(), BT.h:345) — a prefix of the same clock
+    r.T_static = count_sample_times(gate_dt, (1.0 - not_check_ratio) * ((N - 3) * h->params.ts_ctrl));
+    if (r.T_static < 0 || r.T_static > T) r.T_static = T;
     r.dthresh = h->params.dthresh; r.not_check_ratio = not_check_ratio;
     r.flags = count;
     // the optimize() a trajectory still owes (BT.cpp:612 / after a host-side re-guide) ...

@@ -139,7 +139,8 @@ struct ReboundArgs {
     double* weights;
     vigo_rebound_state_t* state;
     double ts_ctrl;
-    int T;
+    int T;                   // samples of the whole trajectory (dynamic gate, BT.h:345)
+    int T_static;            // samples up to (1 - not_check_ratio) * duration (static gate, BT.h:313); <= T
     const double* times;
     double dthresh, not_check_ratio;
     int32_t* flags;          // see k_rebound_compact

@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(64) k_rebound_decide(GridView g, ReboundArgs A
 
     // hasCollisionTrajectory, BT.h:307-325 (same walk as k_traj_collision)
     int col = 0;
-    for (int k = lane; k < A.T && !col; k += 64) {
+    for (int k = lane; k < A.T_static && !col; k += 64) {
         double p[3];
         traj_eval(c, N, A.ts_ctrl, 0, A.times[k], p);
         if (grid_plane_pos(g, 0, p[0], p[1], p[2])) col = 1;

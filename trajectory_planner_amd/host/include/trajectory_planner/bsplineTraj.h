@@ -64,6 +64,7 @@ private:
     vigo_context* dev_ = nullptr;
     uint64_t mapStamp_ = 0;            // mapAdapter's memo of the snapshot this planner's handle holds (0 = none)
     mapRegion mapRegion_;
+    int deviceOrdinal_ = 0;            // HIP device of this planner's handle (setDevice)
     int lastStatus_ = 0;
     bool syncDevice();   // params + map snapshot -> handle; false when no GPU / HIP failure
 
@@ -90,6 +91,9 @@ public:
      * access, see mapAdapter.h; ignored by the in-tree dense map) and the request to re-snapshot a map that changed */
     void setMapRegion(const Eigen::Vector3d& boxMin, const Eigen::Vector3d& boxMax);
     void refreshMap();
+    /* not in the reference: the HIP device ordinal this planner's back-end handle lives on (default 0); call it before
+     * the first plan, or later to move the planner (the handle is re-created and the map uploaded again) */
+    void setDevice(int ordinal);
     void updateMaxVel(double maxVel);
     void updateMaxAcc(double maxAcc);
     bool inputPathCheck(const nav_msgs::Path& path, nav_msgs::Path& adjustedPath, double dt, double& finalTime);

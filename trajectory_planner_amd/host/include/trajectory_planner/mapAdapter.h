@@ -28,6 +28,14 @@ struct mapRegion {
     bool set = false;
     Eigen::Vector3d boxMin, boxMax;   // metric box the planner works in
 };
+// two planners may share one device snapshot only when they would rasterise the same box
+inline bool sameRegion(const mapRegion& a, const mapRegion& b) {
+    if (a.set != b.set) return false;
+    if (!a.set) return true;
+    for (int k = 0; k < 3; ++k)
+        if (a.boxMin(k) != b.boxMin(k) || a.boxMax(k) != b.boxMax(k)) return false;
+    return true;
+}
 
 class mapAdapter {
 public:
@@ -35,6 +43,12 @@ public:
      * yet / refresh requested); it is updated.  false: no region for a map that needs one, or a device failure. */
     static bool uploadSnapshot(vigo_context* dev, const std::shared_ptr<mapManager::occMap>& map, const mapRegion& region,
                                uint64_t& stamp);
+    /* A live map (one the adapter can only rasterise) changed: EVERY handle that snapshotted it is stale, whichever
+     * planner's refreshMap() / updateMap() said so — the generation is per map object, process-wide, and a planner's
+     * `stamp` records the generation its own handle holds (so a batch whose lead never asked for the refresh itself
+     * still re-rasterises).  Generations start at 1; a stamp of 0 never matches. */
+    static uint64_t generation(const mapManager::occMap* map);
+    static void bumpGeneration(const mapManager::occMap* map);
     /* octomap-style node lookup for polyTrajOctomap::checkCollisionPoint (PO.cpp:571-589): kOutside beyond the metric
      * bounds, else bit1 = no node (unknown), bit2 = occupied */
     enum : unsigned { kUnknown = 2u, kOccupied = 4u, kOutside = 0x80u };

@@ -48,6 +48,7 @@ private:
     vigo_context* dev_ = nullptr;
     uint64_t mapStamp_ = 0;             // mapAdapter's memo of the snapshot the handle holds (0 = none)
     mapRegion mapRegion_;
+    int deviceOrdinal_ = 0;             // HIP device of the handle (setDevice)
     int lastIterations_ = 0;
     bool syncDevice();
     bool sweepPoints(const std::vector<pose>& pts, std::vector<uint8_t>& flags);
@@ -92,11 +93,14 @@ public:
     }
     void insertWaypoint(const std::set<int>& seg);                     // PO.cpp:178-186
     /* re-snapshot the map on the next device call (the reference re-fetches /octomap_binary, PO.cpp:133-145) */
-    void updateMap() { mapStamp_ = 0; }
+    void updateMap() { mapAdapter::bumpGeneration(map_.get()); mapStamp_ = 0; }
     /* not in the reference: the box of the map the device snapshot covers (mapAdapter.h; ignored by the dense map) */
     void setMapRegion(const Eigen::Vector3d& boxMin, const Eigen::Vector3d& boxMax) {
         mapRegion_.set = true; mapRegion_.boxMin = boxMin; mapRegion_.boxMax = boxMax; mapStamp_ = 0;
     }
+
+    /* not in the reference: HIP device ordinal of this planner's back-end handle (default 0), see bsplineTraj::setDevice */
+    void setDevice(int ordinal);
 
     bool checkCollision(const pose& p);                                         // box sweep, PO.cpp:547-568
     bool checkCollisionPoint(const pose& p, bool ignoreUnknown = false);        // PO.cpp:571-595

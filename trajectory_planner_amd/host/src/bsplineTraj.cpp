@@ -117,7 +117,20 @@ void bsplineTraj::setMapRegion(const Eigen::Vector3d& boxMin, const Eigen::Vecto
     this->mapStamp_ = 0;
 }
 
-void bsplineTraj::refreshMap() { this->mapStamp_ = 0; }
+void bsplineTraj::refreshMap() {
+    mapAdapter::bumpGeneration(this->map_.get());   // every handle holding a snapshot of this map is stale, not only this planner's
+    this->mapStamp_ = 0;
+}
+
+// one process per GPU is the deployment the back-end is built for (HIP_VISIBLE_DEVICES picks the card); a process that
+// drives several cards gives each planner its ordinal before the planner's first device call.  A planner that already
+// holds a handle on another card lets go of it: the next call creates a new one there and uploads the map again.
+void bsplineTraj::setDevice(int ordinal) {
+    if (ordinal == deviceOrdinal_) return;
+    if (dev_) { vigo_destroy(dev_); dev_ = nullptr; }
+    mapStamp_ = 0;
+    deviceOrdinal_ = ordinal;
+}
 
 void bsplineTraj::updateMaxVel(double maxVel) { this->maxVel_ = maxVel; }
 void bsplineTraj::updateMaxAcc(double maxAcc) { this->maxAcc_ = maxAcc; }
@@ -144,11 +157,11 @@ void bsplineTraj::fillParams(vigo_params_s* Pp) const {
     P.g_epsilon = 0.01;       // BT.cpp:699
 }
 
-// Two planners may share a device batch when the lead's handle state fits both: the same map object, the same
-// control-point count, gate step (maxVel_) and every parameter of fillParams() except the four weights, which
+// Two planners may share a device batch when the lead's handle state fits both: the same map object AND the same
+// box of it to snapshot (setMapRegion), the same control-point count, gate step (maxVel_) and every parameter of fillParams() except the four weights, which
 // travel per trajectory.
 bool bsplineTraj::sameBatchKey(const bsplineTraj& o) const {
-    if (map_ != o.map_ || maxVel_ != o.maxVel_ || notCheckRatio_ != o.notCheckRatio_ ||
+    if (deviceOrdinal_ != o.deviceOrdinal_ || map_ != o.map_ || !sameRegion(mapRegion_, o.mapRegion_) || maxVel_ != o.maxVel_ || notCheckRatio_ != o.notCheckRatio_ ||
         optData_.controlPoints.cols() != o.optData_.controlPoints.cols())
         return false;
     vigo_params_t a, b;
@@ -160,8 +173,13 @@ bool bsplineTraj::sameBatchKey(const bsplineTraj& o) const {
 
 // handle creation, parameter push and (re)snapshot of the map when it changed (mapAdapter)
 bool bsplineTraj::syncDevice() {
+    // the planner's GPU is made current on the calling thread: its stream and staging buffers are per (thread, device)
+    if (hipSetDevice(deviceOrdinal_) != hipSuccess) {
+        cout << "[BsplineTraj]: HIP device " << deviceOrdinal_ << " is not available (there is no CPU fallback)." << endl;
+        return false;
+    }
     if (!dev_) {
-        if (vigo_create(&dev_, 0) != VIGO_OK) {
+        if (vigo_create(&dev_, deviceOrdinal_) != VIGO_OK) {
             cout << "[BsplineTraj]: no HIP device for the ViGO back-end (there is no CPU fallback)." << endl;
             dev_ = nullptr;
             return false;

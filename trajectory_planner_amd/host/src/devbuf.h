@@ -10,14 +10,24 @@ namespace vigo_host {
 // One non-blocking HIP stream per host thread: the facades bind the handle they drive to it (vigo_set_stream), stage
 // their copies on it and wait on it alone, so two host threads planning two batches overlap on the device instead of
 // meeting in hipDeviceSynchronize().  nullptr (the default stream) if the stream cannot be created.
+// The stream belongs to the device that is CURRENT on the calling thread (the facades make their planner's device
+// current first, setDevice()): one per (thread, device ordinal), so planners on different GPUs of one process never
+// share a stream.
+constexpr int kMaxDevices = 64;
+inline int currentDevice() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+    return d;
+}
 inline hipStream_t threadStream() {
-    static thread_local hipStream_t s = nullptr;
-    static thread_local bool tried = false;
-    if (!tried) {
-        tried = true;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+    static thread_local hipStream_t s[kMaxDevices] = {};
+    static thread_local bool tried[kMaxDevices] = {};
+    const int d = currentDevice();
+    if (!tried[d]) {
+        tried[d] = true;
+        if (hipStreamCreateWithFlags(&s[d], hipStreamNonBlocking) != hipSuccess) s[d] = nullptr;
     }
-    return s;
+    return s[d];
 }
 inline bool threadSync() { return hipStreamSynchronize(threadStream()) == hipSuccess; }
 
@@ -25,26 +35,31 @@ inline bool threadSync() { return hipStreamSynchronize(threadStream()) == hipSuc
 struct DevBuf {
     void* p = nullptr;
     size_t n = 0;
+    int dev = -1;        // device the allocation lives on: a buffer reused under another current device is re-made there
     bool keep = false;   // thread-lifetime staging buffers: left to the runtime's teardown, not freed after it
     ~DevBuf() { if (p && !keep) (void)hipFree(p); }
     bool upload(const void* src, size_t bytes) {
-        if (bytes > n) {
+        const int cur = currentDevice();
+        if (bytes > n || (p && dev != cur)) {
             if (p) (void)hipFree(p);
             p = nullptr;
             n = 0;
             if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return false;
             n = bytes;
+            dev = cur;
         }
         // (pageable source: staged by the runtime before the call returns; ordered with the thread's stream)
         return bytes == 0 || hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, threadStream()) == hipSuccess;
     }
     bool alloc(size_t bytes) {
-        if (bytes <= n && p) return true;
+        const int cur = currentDevice();
+        if (bytes <= n && p && dev == cur) return true;
         if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
         if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return false;
         n = bytes;
+        dev = cur;
         return true;
     }
     bool download(void* dst, size_t bytes) const {

@@ -4,6 +4,8 @@
 
 #include <cmath>
 #include <iostream>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../../include/vigo.h"
@@ -34,6 +36,25 @@ bool mapAdapter::rasterise(mapManager::occMap& map, const mapRegion& region, std
     return true;
 }
 
+namespace {
+std::mutex g_genMutex;
+std::map<const mapManager::occMap*, uint64_t> g_generation;
+}  // namespace
+
+uint64_t mapAdapter::generation(const mapManager::occMap* map) {
+    std::lock_guard<std::mutex> lk(g_genMutex);
+    auto it = g_generation.find(map);
+    return it == g_generation.end() ? 1 : it->second;
+}
+
+void mapAdapter::bumpGeneration(const mapManager::occMap* map) {
+    if (!map) return;
+    std::lock_guard<std::mutex> lk(g_genMutex);
+    auto it = g_generation.find(map);
+    if (it == g_generation.end()) g_generation[map] = 2;
+    else ++it->second;
+}
+
 bool mapAdapter::uploadSnapshot(vigo_context* dev, const std::shared_ptr<mapManager::occMap>& map, const mapRegion& region,
                                 uint64_t& stamp) {
     if (!dev || !map) return false;
@@ -45,7 +66,8 @@ bool mapAdapter::uploadSnapshot(vigo_context* dev, const std::shared_ptr<mapMana
     stamp = map->version;
     return true;
 #else
-    if (stamp != 0) return true;          // current until the owner asks for a refresh
+    const uint64_t gen = generation(map.get());
+    if (stamp == gen) return true;        // current until an owner of this map asks for a refresh
     std::vector<uint8_t> vox;
     int dims[3];
     double origin[3];
@@ -54,7 +76,7 @@ bool mapAdapter::uploadSnapshot(vigo_context* dev, const std::shared_ptr<mapMana
         return false;
     }
     if (vigo_set_grid_host(dev, dims[0], dims[1], dims[2], origin, map->getRes(), vox.data()) != VIGO_OK) return false;
-    stamp = 1;
+    stamp = gen;
     return true;
 #endif
 }

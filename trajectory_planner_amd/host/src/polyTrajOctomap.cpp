@@ -51,7 +51,11 @@ void polyTrajOctomap::setMap(const std::shared_ptr<mapManager::occMap>& map) {
 
 bool polyTrajOctomap::syncDevice() {
     if (!map_) return false;
-    if (!dev_ && vigo_create(&dev_, 0) != VIGO_OK) {
+    if (hipSetDevice(deviceOrdinal_) != hipSuccess) {    // this planner's GPU current on the calling thread (stream, staging)
+        cout << "[Trajectory Planner INFO]: HIP device " << deviceOrdinal_ << " is not available (no CPU fallback)." << endl;
+        return false;
+    }
+    if (!dev_ && vigo_create(&dev_, deviceOrdinal_) != VIGO_OK) {
         cout << "[Trajectory Planner INFO]: no HIP device for the corridor checker (no CPU fallback)." << endl;
         dev_ = nullptr;
         return false;
@@ -59,6 +63,14 @@ bool polyTrajOctomap::syncDevice() {
     // launches and staging copies of this call go to the calling thread's stream
     if (vigo_set_stream(dev_, vigo_host::threadStream()) != VIGO_OK) return false;
     return mapAdapter::uploadSnapshot(dev_, map_, mapRegion_, mapStamp_);
+}
+
+// see bsplineTraj::setDevice
+void polyTrajOctomap::setDevice(int ordinal) {
+    if (ordinal == deviceOrdinal_) return;
+    if (dev_) { vigo_destroy(dev_); dev_ = nullptr; }
+    mapStamp_ = 0;
+    deviceOrdinal_ = ordinal;
 }
 
 void polyTrajOctomap::updatePath(const nav_msgs::Path& path) {
@@ -294,15 +306,24 @@ std::vector<bool> polyTrajOctomap::makePlanBatch(const std::vector<polyTrajOctom
     // map or sweep geometry than the first planner's, soft waypoint constraints — the device QP takes the waypoints
     // as equalities) plan on their own
     std::vector<size_t> grp;
+    bool toldSoft = false;
     for (size_t i = 0; i < P; ++i) {
         polyTrajOctomap* p = ps[i];
         p->findValidTraj_ = false;
         const bool batchable = p->extKnots_.empty() && p->path_.size() >= 2 && p->polyDegree_ == 7 && p->diffDegree_ == ps[0]->diffDegree_ &&
                                p->continuityDegree_ == ps[0]->continuityDegree_ && p->desiredVel_ == ps[0]->desiredVel_ &&
-                               p->corridorRes_ == ps[0]->corridorRes_ && p->map_ == ps[0]->map_ && p->collisionBox_ == ps[0]->collisionBox_ &&
+                               p->corridorRes_ == ps[0]->corridorRes_ && p->deviceOrdinal_ == ps[0]->deviceOrdinal_ && p->map_ == ps[0]->map_ && sameRegion(p->mapRegion_, ps[0]->mapRegion_) && p->collisionBox_ == ps[0]->collisionBox_ &&
                                p->mapRes_ == ps[0]->mapRes_ && !p->softConstraint_;
         if (batchable) grp.push_back(i);
-        else { p->makePlan(trajectories[i], p->delT_); result[i] = p->findValidTraj_; }
+        else {
+            if (p->softConstraint_ && !toldSoft) {
+                // (once per call: such a planner leaves the batched device path — the device QP takes waypoints as equalities)
+                cout << "[Trajectory Planner INFO]: soft waypoint constraints: planned on the host path, outside the device batch." << endl;
+                toldSoft = true;
+            }
+            p->makePlan(trajectories[i], p->delT_);
+            result[i] = p->findValidTraj_;
+        }
     }
     if (grp.empty()) return result;
     polyTrajOctomap* lead = ps[grp[0]];
@@ -333,6 +354,9 @@ std::vector<bool> polyTrajOctomap::makePlanBatch(const std::vector<polyTrajOctom
             polyTrajOctomap* p0 = ps[grp[g0]];
             const int W = (int)p0->path_.size(), K = W - 1;
             if (W > kMaxDevWaypoints) {                       // beyond the device QP: the host QP, same algorithm
+                // (corridor mode: the boxes of this round before every solve, like makePlanCorridorConstraint — PO.cpp:421-424;
+                // an infeasible corridor keeps the previous polynomial there as here)
+                if (!p0->mode_) p0->trajSolver_->setCorridorConstraint(st[g0].corridor, p0->corridorRes_);
                 p0->trajSolver_->solve();
                 solved[g0] = true;
                 continue;

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -24,12 +25,21 @@ public:
         cvStart_.notify_all();
         for (auto& t : workers_) t.join();
     }
+    // fn(i) for i in [0, n).  A call made from inside a job of this same pool (the calling thread's fn nesting another
+    // parallelFor) runs serially: the pool has one job slot.  An exception thrown by fn — on the caller or on a worker —
+    // stops the hand-out of further indices, is held until every worker has left the job (they read `job`, which lives
+    // on this frame), and is then rethrown on the caller; the first one wins.
     template <typename F>
     void run(size_t n, unsigned nthr, F& fn) {
-        if (nthr <= 1 || n <= 1) {
+        if (nthr <= 1 || n <= 1 || inRun_) {
             for (size_t i = 0; i < n; ++i) fn(i);
             return;
         }
+        struct Guard {
+            bool& f;
+            explicit Guard(bool& x) : f(x) { f = true; }
+            ~Guard() { f = false; }
+        } guard(inRun_);
         while (workers_.size() + 1 < nthr) workers_.emplace_back([this]() { this->loop(); });
         std::function<void(size_t)> job = [&fn](size_t i) { fn(i); };
         {
@@ -39,14 +49,28 @@ public:
             next_.store(0);
             wanted_ = nthr - 1;          // workers that may join this job (the caller is the nthr-th)
             pending_ = 0;
+            error_ = nullptr;
             ++generation_;
         }
         cvStart_.notify_all();
-        for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) fn(i);
-        std::unique_lock<std::mutex> lk(m_);
-        wanted_ = 0;                     // late wakers find nothing to join
-        cvDone_.wait(lk, [this]() { return pending_ == 0; });
-        job_ = nullptr;
+        std::exception_ptr mine;
+        try {
+            for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) fn(i);
+        } catch (...) {
+            mine = std::current_exception();
+            next_.store(n);              // nobody takes another index
+        }
+        std::exception_ptr theirs;
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            wanted_ = 0;                 // late wakers find nothing to join
+            cvDone_.wait(lk, [this]() { return pending_ == 0; });
+            job_ = nullptr;
+            theirs = error_;
+            error_ = nullptr;
+        }
+        if (mine) std::rethrow_exception(mine);
+        if (theirs) std::rethrow_exception(theirs);
     }
 
 private:
@@ -66,9 +90,16 @@ private:
                 job = job_;
                 n = n_;
             }
-            for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) (*job)(i);
+            std::exception_ptr err;
+            try {
+                for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) (*job)(i);
+            } catch (...) {
+                err = std::current_exception();
+                next_.store(n);
+            }
             {
                 std::lock_guard<std::mutex> lk(m_);
+                if (err && !error_) error_ = err;
                 --pending_;
             }
             cvDone_.notify_one();
@@ -82,6 +113,8 @@ private:
     std::atomic<size_t> next_{0};
     unsigned wanted_ = 0, pending_ = 0, generation_ = 0;
     bool stop_ = false;
+    bool inRun_ = false;                 // only the owning (calling) thread touches it: the pool is thread_local
+    std::exception_ptr error_;           // first exception thrown by a worker's share of the current job
 };
 
 template <typename F>

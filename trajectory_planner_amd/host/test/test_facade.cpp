@@ -488,6 +488,88 @@ int main() {
         CHECK(same == 32 && grown > 0 && validAdding > 0, "polyTrajOctomap::makePlanBatch, adding-waypoint mode: batch plan == single makePlan");
     }
 
+    // ---- a corridor-mode path of MORE waypoints than the device QP takes (13 > 11) inside a batch: solved by the host QP
+    //      inside the same rounds, WITH the round's corridor boxes (PO.cpp:421-424) — the same plan as the planner alone ----
+    {
+        auto mk = [&](double y0, int W) {
+            ros::NodeHandle nh;
+            nh.setParam("collision_box", std::vector<double>{0.4, 0.4, 0.2});
+            nh.setParam("map_resolution", 0.2);
+            nh.setParam("sample_delta_time", 0.1);
+            nh.setParam("mode", 0.0);
+            nh.setParam("initial_radius", 0.5);
+            nh.setParam("shrinking_factor", 0.8);
+            nh.setParam("corridor_res", 8.0);
+            nh.setParam("maximum_iteration_num", 30.0);
+            nh.setParam("traj_timeout", 5.0);
+            std::unique_ptr<trajPlanner::polyTrajOctomap> q(new trajPlanner::polyTrajOctomap(nh));
+            q->setMap(map);
+            std::vector<trajPlanner::pose> wp;
+            for (int i = 0; i < W; ++i) {
+                const double x = -3.0 + 6.0 * i / (W - 1);
+                wp.push_back(trajPlanner::pose(x, y0 + 0.25 * ((i % 2) ? 1.0 : -1.0) * (i > 0 && i + 1 < W), 1));   // a zig-zag: the free QP swings wide
+            }
+            q->updatePath(wp);
+            return q;
+        };
+        std::vector<std::unique_ptr<trajPlanner::polyTrajOctomap>> owners, twins;
+        std::vector<trajPlanner::polyTrajOctomap*> ps;
+        const double ys[4] = {1.25, 1.45, 1.6, 2.4};
+        for (int i = 0; i < 4; ++i) { owners.push_back(mk(ys[i], 13)); twins.push_back(mk(ys[i], 13)); ps.push_back(owners.back().get()); }
+        for (int i = 0; i < 4; ++i) { owners.push_back(mk(ys[i], 5)); twins.push_back(mk(ys[i], 5)); ps.push_back(owners.back().get()); }
+        std::vector<std::vector<trajPlanner::pose>> trajs;
+        std::vector<bool> res = trajPlanner::polyTrajOctomap::makePlanBatch(ps, trajs);
+        int same = 0, shrunk = 0, validLong = 0;
+        double worst = 0;
+        for (size_t i = 0; i < ps.size(); ++i) {
+            std::vector<trajPlanner::pose> t2;
+            twins[i]->makePlan(t2, 0.1);
+            bool eq = twins[i]->isValid() == res[i] && t2.size() == trajs[i].size() && twins[i]->getIterations() == ps[i]->getIterations();
+            double w = 0;
+            for (size_t k = 0; eq && k < t2.size(); ++k)
+                w = std::fmax(w, std::fabs(t2[k].x - trajs[i][k].x) + std::fabs(t2[k].y - trajs[i][k].y) + std::fabs(t2[k].z - trajs[i][k].z));
+            eq = eq && w < 1e-6;
+            worst = std::fmax(worst, w);
+            same += eq;
+            if (i < 4) { shrunk += ps[i]->getIterations() > 1; validLong += res[i]; }
+        }
+        std::printf("INFO poly batch with 13-waypoint corridor planners: %d of 8 identical to the planner alone (max diff %.3e); of the 4 long paths %d valid, %d needed a shrunk corridor\n",
+                    same, worst, validLong, shrunk);
+        CHECK(same == 8 && shrunk > 0, "a 13-waypoint corridor-mode planner in a batch is planned with its corridor boxes: batch plan == single makePlan");
+    }
+
+    // ---- the device ordinal of a planner (setDevice): ordinal 0 again after a plan re-creates the handle and re-uploads the
+    //      map with the same result; an ordinal the machine does not have is refused without a crash ----
+    {
+        bsplineTraj a(makeParams()), b(makeParams());
+        a.setMap(map);
+        b.setMap(map);
+        nav_msgs::Path path = straight(-3.0, 0.1, 3.0, 0.1, 1.0, 0.25);
+        std::vector<Eigen::Vector3d> cond(4, Eigen::Vector3d(0, 0, 0));
+        b.setDevice(0);
+        const bool okA = a.updatePath(path, cond) && a.makePlan();
+        bool okB = b.updatePath(path, cond) && b.makePlan();
+        b.setDevice(1 << 20);                              // no such card
+        const bool refused = !(b.updatePath(path, cond) && b.makePlan());
+        b.setDevice(0);                                    // back: a new handle, the map uploaded again
+        okB = okB && b.updatePath(path, cond) && b.makePlan();
+        const Eigen::MatrixXd ca = a.getControlPoints(), cb = b.getControlPoints();
+        bool eq = ca.cols() == cb.cols();
+        for (int i = 0; eq && i < ca.cols(); ++i) for (int k = 0; k < 3; ++k) eq = eq && ca(k, i) == cb(k, i);
+        CHECK(okA && okB && refused && eq, "setDevice: ordinal 0 plans as the default does, a missing card is refused, moving back re-creates the handle");
+        ros::NodeHandle nh;
+        nh.setParam("collision_box", std::vector<double>{0.4, 0.4, 0.2});
+        nh.setParam("map_resolution", 0.2);
+        trajPlanner::polyTrajOctomap poly(nh);
+        poly.setMap(map);
+        poly.setDevice(0);
+        const bool hit0 = poly.checkCollision(trajPlanner::pose(0, 0, 1));
+        poly.setDevice(1 << 20);
+        const bool hitNo = poly.checkCollision(trajPlanner::pose(-3, 0, 1));   // no device: "colliding" (flags default to 1), no crash
+        poly.setDevice(0);
+        CHECK(hit0 && hitNo && !poly.checkCollision(trajPlanner::pose(-3, 0, 1)), "polyTrajOctomap::setDevice: same, and back");
+    }
+
     // ---- degenerate inputs: the classes answer false / "not found", never crash ----
     {
         const double nan = std::nan("");
