@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and other-arithmetic-mode side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1 only: create the RCCL process group anyway (world size 1) and make exactly the collective calls "
+                         "the N > 1 path makes — broadcast of the packed snapshot, all_reduce MIN/MAX on fp64 device tensors, barrier — "
+                         "so RCCL's library load, dtypes and ops are exercised on a one-GPU box")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal of the N > 1 rank logic on a one-GPU box: every rank uses cuda:0 and the collectives "
                          "go over gloo (host-staged); timings are meaningless, the printed line is marked")
@@ -123,6 +127,40 @@ def cpu_baseline(args, seconds, threads):
     return sum(d for d, _ in res) / wall, sum(d for d, _ in res)
 
 
+def pmc_view(precision, name, kern_ms, waves, simds, lib_build_id, suffix=""):
+    """Counter evidence for one quoted shape: profiles/pmc_<name>_<precision><suffix>.json (rocprofv3 --pmc passes of this
+    very command, summarised by tools/summarize_pmc.py).  The counters are a committed record, not measured in this run:
+    `pmc_stale` says whether the solve kernels' sources have changed since they were taken (vigo_build_id's solver hash
+    against the file's)."""
+    path = os.path.join(ROOT, "profiles", f"pmc_{name}_{precision}{suffix}.json")
+    if not os.path.exists(path):
+        return {"pmc_source": None}
+    try:
+        pmc = json.load(open(path))
+    except Exception:
+        return {"pmc_source": None}
+    cnt = pmc.get("counters_per_launch", {})
+    valu = cnt.get("SQ_INSTS_VALU")
+    kernel_cycles = kern_ms * 1e-3 * SHADER_CLOCK_GHZ * 1e9
+    traffic = pmc.get("hbm_bytes_per_launch")
+    solver_now = lib_build_id.split()[0] if lib_build_id else None
+    solver_then = str(pmc.get("build_id", "")).split()[0] if pmc.get("build_id") else None
+    out = {"traffic": traffic,
+           "issue_frac": (valu * VALU_ISSUE_CYCLES / (simds * kernel_cycles)) if valu else None,
+           "issue_frac_of_occupied_simds": (valu * VALU_ISSUE_CYCLES / (min(waves, simds) * kernel_cycles)) if valu else None,
+           "valu_insts_per_wave": (valu / cnt["SQ_WAVES"]) if valu and cnt.get("SQ_WAVES") else None,
+           "measured_hbm_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+           "pmc_source": os.path.relpath(path, ROOT) + " (" + str(pmc.get("build_id") or pmc.get("build", "build not recorded")) + ")",
+           "pmc_stale": solver_then != solver_now}
+    if cnt.get("SQ_ACTIVE_INST_VALU") and cnt.get("SQ_WAVE_CYCLES"):
+        # share of the waves' lifetime during which a VALU instruction of theirs was executing
+        out["valu_busy_of_wave_lifetime"] = cnt["SQ_ACTIVE_INST_VALU"] / cnt["SQ_WAVE_CYCLES"]
+    if cnt.get("SQ_WAIT_INST_ANY") and cnt.get("SQ_WAVE_CYCLES"):
+        out["memory_wait_of_wave_lifetime"] = cnt["SQ_WAIT_INST_ANY"] / cnt["SQ_WAVE_CYCLES"]
+        out["wait_inst_any_wave_cycles"] = cnt["SQ_WAIT_INST_ANY"]
+    return out
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -158,10 +196,16 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world_size > 1:
+    use_dist = world_size > 1 or args.force_collectives
+    if use_dist:
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
+            if world_size == 1:      # --force-collectives outside torch.distributed.run: a rendezvous of one
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29577")
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
             dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
 
     # Rehearsal (gloo, every rank on cuda:0) takes the SAME tensor placement as the real runs — device tensors handed
@@ -200,7 +244,7 @@ def main():
         else:
             packed_ = torch.empty(nwords, dtype=torch.int32, device=dev)
         ms = 0.0
-        if world_size > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             t_b0 = time.perf_counter()
@@ -235,23 +279,23 @@ def main():
         for _ in range(warmup):
             one()
         torch.cuda.synchronize()
-        if world_size > 1:
+        if use_dist:
             dist.barrier()
         t_0 = time.perf_counter()
         for i in range(steps):
             one(i)
         torch.cuda.synchronize()
-        if world_size > 1:
+        if use_dist:
             dist.barrier()
         el = time.perf_counter() - t_0
-        if world_size > 1:
+        if use_dist:
             el = max_over_ranks(el)
         return el, float(np.mean([x.elapsed_time(y) for x, y in zip(e0, e1)])), res_, (ctrl0_, goff_, gpv_, work_, one)
 
     packed, bcast_ms = install_map(v, world)
     dims = world.voxels.shape
     snapshot_ok = None
-    if world_size > 1:
+    if use_dist:
         # every rank answers the same seeded point queries from the snapshot it adopted; the answers must agree
         qp = T(np.random.default_rng(99).uniform(world.origin.min() - 0.5, -world.origin.min() + 0.5, size=(4096, 3)))
         sig = torch.stack([v.query_points(qp, w).to(torch.float64) @ torch.arange(1, 4097, dtype=torch.float64, device=dev)
@@ -269,6 +313,7 @@ def main():
     evals = res.evals.cpu().numpy()
 
     simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+    build_id = v._lib.vigo_build_id().decode()
     # ---- side measurements (outside the timed region above; rank 0 of a single-GPU run only) ----
     extra = {}
     if rank == 0 and world_size == 1 and not args.no_extras:
@@ -369,13 +414,47 @@ def main():
         if args.workload == "config2":
             from trajectory_planner_amd import synth
             big = synth.make_bspline_batch(world, 16384, 32, synth.SEED_BASE + 2 + 5000)
-            el, kms, r_big, _ = timed_solves(v, big, max(5, args.steps // 20), 2)
-            extra["config2_at_16384"] = {"value": 16384 * max(5, args.steps // 20) / el, "unit": "trajectories/s", "kernel_ms": kms,
+            kb = max(5, args.steps // 20)
+            el, kms, r_big, _ = timed_solves(v, big, kb, 2)
+            extra["config2_at_16384"] = {"value": 16384 * kb / el, "unit": "trajectories/s", "kernel_ms": kms,
                                          "simd_occupancy": min(1.0, (16384 // 2) / simds), "note": "same map, B = 16384 x 32; never `value`"}
+            extra["config2_at_16384"].update(pmc_view(args.precision, "config2", kms, 16384 // 2, simds, build_id, "_b16384"))
             del big, r_big
+            # (e2) configs[1] on guides from the planner's OWN host pipeline (findCollisionSeg -> A* -> assignGuidePointsSemiCircle,
+            #      bsplineTraj.cpp:403-571, through libtrajectory_planner_vigo.so — product code) in a world dense enough that
+            #      over half the trajectories cross an obstacle; then the same trajectories two re-guides later
+            #      (bsplineTraj.cpp:640-648 replayed on the optimizer's output: pairs are APPENDED, the next solve starts
+            #      from the moved control points).  Never `value`.
+            try:
+                pw = synth.make_pipeline_world()
+                vp = Vigo(local_rank, P, prec_code[args.precision])
+                vp.use_current_stream()
+                vp.set_grid(T(pw.voxels), pw.origin, pw.res)
+                pb = synth.make_pipeline_batch(pw, 1024, 32, synth.SEED_BASE + 2 + 2000)
+                rec = {"workload": "configs[1] shape (1024 x 32, 256^3, %d iterations) in the dense world, guides from the host pipeline" % args.iters,
+                       "stages": []}
+                for stage in range(3):
+                    hist, per_traj, share = synth.pairs_histogram(pb)
+                    elp, kmsp, rp, _ = timed_solves(vp, pb, kb * 2, 2)
+                    rec["stages"].append({"reguides": stage, "guide_pairs": int(pb.guide_pv.shape[0]),
+                                          "pairs_per_trajectory_mean": float(per_traj.mean()), "pairs_per_trajectory_max": int(per_traj.max()),
+                                          "trajectories_with_guides": share, "max_pairs_per_point": int(len(hist) - 1),
+                                          "pairs_per_free_point_histogram": [int(x) for x in hist],
+                                          "kernel_ms": kmsp, "value": 1024 * kb * 2 / elp, "unit": "trajectories/s",
+                                          "mean_iters": float(rp.iters.float().mean().item()), "mean_evals": float(rp.evals.float().mean().item())})
+                    if stage < 2:
+                        pb = synth.reguide_batch(pw, pb, rp.ctrl.cpu().numpy())
+                rec["kernel_ms"] = rec["stages"][0]["kernel_ms"]
+                rec["guide_pairs"] = rec["stages"][0]["guide_pairs"]
+                extra["config2_pipeline_guides"] = rec
+                vp.close()
+                del pw, pb
+            except (RuntimeError, OSError) as e:      # the host facade library is not built: say so, do not invent numbers
+                extra["config2_pipeline_guides"] = {"error": str(e)}
     # (f) one GPU's shard of BASELINE configs[3] (8192 x 64 control points, 512^3 map) on every rank count, so the
     #     1 -> 8 record covers the configuration BASELINE names for 8 GPUs; never `value`
     if args.workload == "config2" and not args.no_extras:
+        from trajectory_planner_amd import sharding, synth
         args4 = argparse.Namespace(**vars(args))
         args4.workload, args4.batch = "config4", 0
         world4, batch4, name4 = workload(args4, rank, world_size)
@@ -388,8 +467,27 @@ def main():
                                   "ms_per_step": el4 / k4 * 1e3, "kernel_ms": kms4, "map_bcast_ms": bcast4_ms, "steps": k4,
                                   "simd_occupancy": min(1.0, batch4.B / simds), "mean_iters": float(r4.iters.float().mean().item()),
                                   "note": "whole-job aggregate over all ranks (max-over-ranks time); never `value`"}
+        extra["config4_shard"].update(pmc_view(args.precision, "config4", kms4, batch4.B, simds, build_id))
+        del batch4, r4
+        # (g) BASELINE configs[3] as ONE batch: 65 536 x 64 trajectories seeded once (every rank generates the same batch),
+        #     cut into contiguous slices with sharding.shard_range / slice_batch, rank r solves slice r — strong scaling of
+        #     the named configuration; at N = 1 the whole batch runs on the one GPU.  Max-over-ranks time, aggregate rate.
+        B4 = 65536
+        full4 = synth.make_bspline_batch(world4, B4, 64, synth.SEED_BASE + 4 + 7000, start_range=16.0)
+        lo4, hi4 = sharding.shard_range(B4, rank, world_size)
+        mine4 = sharding.slice_batch(full4, lo4, hi4)
+        del full4
+        ks = max(3, args.steps // 40)
+        els, kmss, rs4, _ = timed_solves(v4, mine4, ks, 1)
+        bounds = [list(sharding.shard_range(B4, r, world_size)) for r in range(world_size)]
+        extra["config4_strong"] = {"workload": f"configs[3]: ONE batch of {B4} B-spline trajs x 64 ctrl pts, 512^3 voxel grid, {args.iters} L-BFGS iters, "
+                                               f"cut into {world_size} contiguous slice(s)",
+                                   "value": B4 * ks / els, "unit": "trajectories/s", "n_gpus": world_size, "scaling": "strong",
+                                   "ms_per_step": els / ks * 1e3, "kernel_ms_rank0": kmss, "steps": ks, "slice_bounds": bounds,
+                                   "slice_rank0": [lo4, hi4], "mean_iters_rank0": float(rs4.iters.float().mean().item()),
+                                   "note": "whole-job aggregate (max-over-ranks time); one seeded batch sliced by rank; never `value`"}
         v4.close()
-        del world4, batch4, r4
+        del world4, mine4, rs4
     gp = np.diff(batch.guide_off).reshape(B, N).sum(1)
     elem = 4 if args.precision == "f32" else 8
     alg_bytes = float(algorithmic_bytes(n, P.mem_size, iters, evals, gp, elem).sum())
@@ -397,23 +495,12 @@ def main():
 
     if rank == 0:
         total = B * world_size * args.steps
-        traffic = None
-        pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.workload}_{args.precision}.json")
-        if os.path.exists(pmc_path) and not args.batch:
-            try:
-                pmc = json.load(open(pmc_path))
-                traffic = pmc.get("hbm_bytes_per_launch")
-            except Exception:
-                pmc, traffic = {}, None
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         tpb = 2 if N <= 32 else 1                       # trajectories per solver wavefront (vigo_solver.hip)
         waves = (B + tpb - 1) // tpb
-        kernel_cycles = kern_ms * 1e-3 * SHADER_CLOCK_GHZ * 1e9
-        cnt = pmc.get("counters_per_launch", {})
-        valu = cnt.get("SQ_INSTS_VALU")
+        pv = pmc_view(args.precision, args.workload, kern_ms, waves, simds, build_id) if not args.batch else {"pmc_source": None}
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pv.get("traffic"),
                 "kernel": "vigo::k_optimize", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
                 "byte_model": "SURVEY.md §8(d) streaming model x fp64 (state streamed per BLAS-1 pass, as the CPU "
                               "reference does); the kernel keeps that state in LDS/VGPRs, so HBM sees only the "
@@ -424,17 +511,8 @@ def main():
                 # 4 cycles, so the chip retires at most SIMDs / 4 wave-instructions per cycle.
                 "binding": "valu_issue",
                 "simds": simds, "waves_per_launch": waves, "simd_occupancy": min(1.0, waves / simds),
-                "shader_clock_ghz": SHADER_CLOCK_GHZ,
-                "issue_frac": (valu * VALU_ISSUE_CYCLES / (simds * kernel_cycles)) if valu else None,
-                "issue_frac_of_occupied_simds": (valu * VALU_ISSUE_CYCLES / (min(waves, simds) * kernel_cycles)) if valu else None,
-                "valu_insts_per_wave": (valu / cnt["SQ_WAVES"]) if valu and cnt.get("SQ_WAVES") else None,
-                "measured_hbm_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "pmc_source": (os.path.relpath(pmc_path, ROOT) + " (" + str(pmc.get("build", "build not recorded")) + ")") if pmc else None}
-        if cnt.get("SQ_ACTIVE_INST_VALU") and cnt.get("SQ_WAVE_CYCLES"):
-            # share of the waves' lifetime during which a VALU instruction of theirs was executing
-            roof["valu_busy_of_wave_lifetime"] = cnt["SQ_ACTIVE_INST_VALU"] / cnt["SQ_WAVE_CYCLES"]
-        if cnt.get("SQ_WAIT_INST_ANY") and cnt.get("SQ_WAVE_CYCLES"):
-            roof["memory_wait_of_wave_lifetime"] = cnt["SQ_WAIT_INST_ANY"] / cnt["SQ_WAVE_CYCLES"]
+                "shader_clock_ghz": SHADER_CLOCK_GHZ, "library_build_id": build_id}
+        roof.update({k: x for k, x in pv.items() if k != "traffic"})
         out = {
             "metric": "B-spline trajs/s (32 ctrl pts, 256^3 grid, 50 iters) @1 GPU; % HBM roofline"
             if args.workload == "config2" else "B-spline trajs/s (64 ctrl pts, 512^3 grid, 50 iters)",
@@ -457,6 +535,10 @@ def main():
                        "mean_iters": float(iters.mean()), "mean_evals": float(evals.mean())},
             "map_bcast_ms": bcast_ms,
             "map_snapshot_identical_on_all_ranks": snapshot_ok,
+            "collectives": None if not use_dist else {
+                "backend": dist.get_backend(), "world_size": dist.get_world_size(), "forced_at_world_size_1": bool(args.force_collectives and world_size == 1),
+                "calls": ["barrier", "broadcast(int32 packed snapshot, %d words)" % packed.numel(), "all_reduce(MIN, f64)", "all_reduce(MAX, f64)"],
+                "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None},
             "roofline": roof,
         }
         out.update(extra)
@@ -471,7 +553,7 @@ def main():
                                             "kind": "port", "sample": f"{cpu['all_n']} solves, one process per host core"}
         print(json.dumps(out))
     v.close()
-    if world_size > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -128,6 +128,9 @@ const char* vigo_last_error(vigo_handle_t h);
 /* Library/ABI version, and whether the code object was built for gfx950. */
 int vigo_abi_version(void);
 const char* vigo_build_arch(void);
+/* "solver:<12 hex> all:<12 hex>": content hashes of the library's sources at build time (the first over the files that
+ * decide the solve kernels' code).  Profiles record it, so a counter file can be told from a stale one. */
+const char* vigo_build_id(void);
 
 /* ---- voxel map ------------------------------------------------------------------- */
 

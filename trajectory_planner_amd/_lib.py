@@ -61,6 +61,7 @@ PROTOTYPES = {
     "vigo_last_error": (C.c_char_p, [_vp]),
     "vigo_abi_version": (_i, []),
     "vigo_build_arch": (C.c_char_p, []),
+    "vigo_build_id": (C.c_char_p, []),
     "vigo_set_grid": (_i, [_vp, _i, _i, _i, _d3, _d, _vp]),
     "vigo_set_grid_host": (_i, [_vp, _i, _i, _i, _d3, _d, _vp]),
     "vigo_inflate_grid": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i]),

@@ -9,6 +9,7 @@
 
 #include "vigo_exact_pow.hpp"
 #include "vigo_exact_time.hpp"
+#include "build/vigo_build_id.h"
 #include "vigo_internal.hpp"
 
 using vigo::DevConst;
@@ -190,6 +191,7 @@ double vigo_exact_pow(double t, int d) {
 }
 double vigo_exact_pow_integer(double t, int d) { return (d < 0 || d > 15) ? NAN : vigo::pow_exact(t, d); }
 const char* vigo_build_arch(void) { return "gfx950"; }
+const char* vigo_build_id(void) { return VIGO_BUILD_ID; }
 
 void vigo_default_params(vigo_params_t* p) {
     if (!p) return;

@@ -147,6 +147,9 @@ public:
     double getTimestep();
     Eigen::MatrixXd getControlPoints();
     const optData& getOptData() const { return optData_; }   /* added (tests): guide points / directions as the optimizer gets them */
+    /* added (workload tools, cabi_host.cpp): take these control points as the planner's current ones with empty guide
+     * lists — the state updatePath() leaves (BT.cpp:315-322) — so the host steps of the rebound loop can be replayed on them */
+    void setControlPoints(const Eigen::MatrixXd& controlPoints) { installControlPoints(controlPoints, {}); }
     bool isCurrTrajValid();
     bool isCurrTrajValid(Eigen::Vector3d& firstCollisionPos);
     int getLastSolverStatus() const { return lastStatus_; }

@@ -13,6 +13,9 @@
 
 #include <chrono>
 #include <cstring>
+#include <mutex>
+
+#include "workerPool.h"
 
 extern "C" {
 
@@ -243,6 +246,121 @@ int vigo_host_poly_plan(int nx, int ny, int nz, const double* origin, double res
     info_out[2] = (double)traj.size();
     info_out[3] = planner.getDuration();
     info_out[4] = secs;
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- the same prologue for MANY paths on ONE map (the workload generator of bench.py / tests: product code, no oracle) ----
+namespace {
+// planners parked between jobs: each owns an A* node pool sized by max_obstacle_size, shares the map
+struct PlannerPool {
+    std::shared_ptr<mapManager::occMap> map;
+    ros::NodeHandle nh;
+    std::mutex m;
+    std::vector<std::unique_ptr<trajPlanner::bsplineTraj>> idle;
+    std::unique_ptr<trajPlanner::bsplineTraj> take() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (!idle.empty()) { auto p = std::move(idle.back()); idle.pop_back(); return p; }
+        }
+        std::unique_ptr<trajPlanner::bsplineTraj> p(new trajPlanner::bsplineTraj(nh));
+        p->setMap(map);
+        return p;
+    }
+    void give(std::unique_ptr<trajPlanner::bsplineTraj> p) {
+        std::lock_guard<std::mutex> lk(m);
+        idle.push_back(std::move(p));
+    }
+};
+
+void initPool(PlannerPool& pool, const unsigned char* vox, const int* dims, const double* origin, double res, const double* cfg) {
+    pool.map = std::make_shared<mapManager::occMap>(dims[0], dims[1], dims[2], Eigen::Vector3d(origin[0], origin[1], origin[2]), res);
+    std::memcpy(pool.map->voxels().data(), vox, pool.map->voxels().size());
+    pool.nh.setParam("bspline_traj/distance_threshold", cfg[0]);
+    pool.nh.setParam("bspline_traj/min_height", cfg[1]);
+    pool.nh.setParam("bspline_traj/max_height", cfg[2]);
+    pool.nh.setParam("bspline_traj/max_obstacle_size", std::vector<double>{cfg[3], cfg[4], cfg[5]});
+    pool.nh.setParam("bspline_traj/max_path_length", 1000.0);
+}
+
+// guide pairs of one planner, control point by control point in push order, into one trajectory's slot of the
+// per-trajectory staging (cnt[N], pairs appended to pv)
+void collectGuides(const trajPlanner::optData& od, int N, std::vector<int>& cnt, std::vector<double>& pv) {
+    cnt.assign(N, 0);
+    pv.clear();
+    for (int i = 0; i < N; ++i) {
+        cnt[i] = (int)od.guidePoints[i].size();
+        for (size_t j = 0; j < od.guidePoints[i].size(); ++j) {
+            for (int k = 0; k < 3; ++k) pv.push_back(od.guidePoints[i][j](k));
+            for (int k = 0; k < 3; ++k) pv.push_back(od.guideDirections[i][j](k));
+        }
+    }
+}
+}  // namespace
+
+extern "C" {
+
+// n paths of n_pts poses each (xyz) on one dense byte grid -> per path: status (0 planned, -1 updatePath refused the path or
+// the control-point count is not N, -2 A* failed: no guides), N control points, the number of collision segments after
+// pathSearch, and the guide pairs of makePlan()'s prologue (BT.cpp:333-350) as CSR over n * N control points:
+// guide_off[n * N + 1], guide_pv[6 per pair] (at most cap_pairs; -2 is returned when they do not fit).
+// ctrl_in != NULL: SKIP updatePath and replay the host steps the rebound loop takes at failCount >= 4 (BT.cpp:640-648:
+// findCollisionSeg -> pathSearch -> assignGuidePointsSemiCircle) on these CURRENT control points [n][N][3], starting from
+// empty lists: the pairs returned are the ones that step would APPEND.  cfg as in vigo_host_bspline_prologue.
+int vigo_host_bspline_guides_batch(const unsigned char* vox, const int* dims, const double* origin, double res, int n, int n_pts,
+                                   const double* path_xyz, const double* ctrl_in, int N, const double* cfg, double* ctrl_out, int* status,
+                                   int* n_seg, int* guide_off, double* guide_pv, long long cap_pairs) {
+    if (n < 0 || N < 7 || (!path_xyz && !ctrl_in)) return -1;
+    PlannerPool pool;
+    initPool(pool, vox, dims, origin, res, cfg);
+    std::vector<std::vector<int>> cnt(n);
+    std::vector<std::vector<double>> pv(n);
+    vigo_host::parallelFor((size_t)n, [&](size_t t) {
+        auto bt = pool.take();
+        status[t] = 0;
+        n_seg[t] = 0;
+        cnt[t].assign(N, 0);
+        bool have = true;
+        if (ctrl_in) {
+            Eigen::MatrixXd c(3, N);
+            for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) c(k, i) = ctrl_in[((size_t)t * N + i) * 3 + k];
+            bt->setControlPoints(c);
+        } else {
+            nav_msgs::Path path;
+            for (int i = 0; i < n_pts; ++i) {
+                geometry_msgs::PoseStamped ps;
+                const double* q = path_xyz + ((size_t)t * n_pts + i) * 3;
+                ps.pose.position.x = q[0]; ps.pose.position.y = q[1]; ps.pose.position.z = q[2];
+                path.poses.push_back(ps);
+            }
+            have = bt->updatePath(path, std::vector<Eigen::Vector3d>(4, Eigen::Vector3d(0, 0, 0))) && bt->getControlPoints().cols() == N;
+        }
+        if (!have) {
+            status[t] = -1;
+        } else {
+            const Eigen::MatrixXd c = bt->getControlPoints();
+            if (ctrl_out) for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) ctrl_out[((size_t)t * N + i) * 3 + k] = c(k, i);
+            std::vector<std::pair<int, int>> seg;
+            std::vector<std::vector<Eigen::Vector3d>> paths;
+            bt->findCollisionSeg(c, seg);
+            if (!bt->pathSearch(seg, paths)) {
+                status[t] = -2;
+            } else {
+                bt->assignGuidePointsSemiCircle(paths, seg);
+                n_seg[t] = (int)seg.size();
+                collectGuides(bt->getOptData(), N, cnt[t], pv[t]);
+            }
+        }
+        pool.give(std::move(bt));
+    });
+    long long g = 0;
+    for (int t = 0; t < n; ++t)
+        for (int i = 0; i < N; ++i) { guide_off[(size_t)t * N + i] = (int)g; g += cnt[t][i]; }
+    guide_off[(size_t)n * N] = (int)g;
+    if (g > cap_pairs) return -2;
+    long long w = 0;
+    for (int t = 0; t < n; ++t) { std::memcpy(guide_pv + 6 * w, pv[t].data(), pv[t].size() * sizeof(double)); w += (long long)pv[t].size() / 6; }
     return 0;
 }
 

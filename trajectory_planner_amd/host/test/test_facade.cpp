@@ -506,15 +506,18 @@ int main() {
             q->setMap(map);
             std::vector<trajPlanner::pose> wp;
             for (int i = 0; i < W; ++i) {
+                // a straight line at y0 with ONE waypoint pulled 1.3 m aside just before the pillar: the free min-snap
+                // polynomial rings and undershoots y0 by ~7.5 cm over the pillar (into its voxels for y0 <= 1.07), and
+                // only a corridor shrunk below ~0.17 m holds it back (host QP, tools: vigo_host_minsnap)
                 const double x = -3.0 + 6.0 * i / (W - 1);
-                wp.push_back(trajPlanner::pose(x, y0 + 0.25 * ((i % 2) ? 1.0 : -1.0) * (i > 0 && i + 1 < W), 1));   // a zig-zag: the free QP swings wide
+                wp.push_back(trajPlanner::pose(x, y0 + ((W == 13 && i == 5) ? 1.3 : 0.0), 1));
             }
             q->updatePath(wp);
             return q;
         };
         std::vector<std::unique_ptr<trajPlanner::polyTrajOctomap>> owners, twins;
         std::vector<trajPlanner::polyTrajOctomap*> ps;
-        const double ys[4] = {1.25, 1.45, 1.6, 2.4};
+        const double ys[4] = {1.04, 1.06, 1.07, 2.4};
         for (int i = 0; i < 4; ++i) { owners.push_back(mk(ys[i], 13)); twins.push_back(mk(ys[i], 13)); ps.push_back(owners.back().get()); }
         for (int i = 0; i < 4; ++i) { owners.push_back(mk(ys[i], 5)); twins.push_back(mk(ys[i], 5)); ps.push_back(owners.back().get()); }
         std::vector<std::vector<trajPlanner::pose>> trajs;
@@ -531,9 +534,9 @@ int main() {
             eq = eq && w < 1e-6;
             worst = std::fmax(worst, w);
             same += eq;
-            if (i < 4) { shrunk += ps[i]->getIterations() > 1; validLong += res[i]; }
+            if (i < 4) { shrunk += ps[i]->getIterations() > 1 && res[i]; validLong += res[i]; }
         }
-        std::printf("INFO poly batch with 13-waypoint corridor planners: %d of 8 identical to the planner alone (max diff %.3e); of the 4 long paths %d valid, %d needed a shrunk corridor\n",
+        std::printf("INFO poly batch with 13-waypoint corridor planners: %d of 8 identical to the planner alone (max diff %.3e); of the 4 long paths %d valid, %d of them only after the corridor had shrunk\n",
                     same, worst, validLong, shrunk);
         CHECK(same == 8 && shrunk > 0, "a 13-waypoint corridor-mode planner in a batch is planned with its corridor boxes: batch plan == single makePlan");
     }
