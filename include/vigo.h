@@ -399,6 +399,12 @@ int vigo_set_esdf(vigo_handle_t h, int nx, int ny, int nz, const double origin[3
                   double res, const float* dist_dev);
 int vigo_esdf_query(vigo_handle_t h, int64_t Q, const double* pts,
                     double* out_dist, double* out_grad);
+/* The same query at the I/O width SURVEY.md §8(d) config 5 states for the fp32 lattice: pts float[Q][3] in (12 B),
+ * out float[Q][4] = {distance, d/dx, d/dy, d/dz} out (16 B, 16-byte aligned), all arithmetic in fp32, every operation
+ * rounded once: u = (p - (float)origin) * inv_res - 0.5f with inv_res = 1.0f / (float)res, floorf, clamps, the blend
+ * x then y then z, gradient differences * inv_res.  Own definition (no reference counterpart); oracle twin
+ * vgo_esdf_query_f32.  Differs from the fp64 entry by fp32 rounding only (~1e-6 relative). */
+int vigo_esdf_query_f32(vigo_handle_t h, int64_t Q, const float* pts, float* out_dist_grad);
 
 #ifdef __cplusplus
 }

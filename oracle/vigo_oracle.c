@@ -1316,6 +1316,52 @@ void vgo_esdf_query(int nx, int ny, int nz, const double origin[3], double res, 
     out_g[2] = (c1 - c0) / res;
 }
 
+/* The fp32 twin of the query (include/vigo.h vigo_esdf_query_f32): the same definition with every operation in float,
+ * each rounded once (-ffp-contract=off; FLT_EVAL_METHOD == 0 on x86-64), the lattice scale as ONE float reciprocal.
+ * out4 = {d, gx, gy, gz}. */
+void vgo_esdf_query_f32(int nx, int ny, int nz, const double origin[3], double res, const float* dist,
+                        const float p[3], float out4[4]) {
+    int n[3] = {nx, ny, nz};
+    int i0[3];
+    float f[3];
+    const float inv_res = 1.0f / (float)res;
+    for (int a = 0; a < 3; ++a) {
+        float u = (p[a] - (float)origin[a]) * inv_res - 0.5f;
+        float fl = floorf(u);
+        int i;
+        float fr = u - fl;
+        if (!(fl >= 0.0f)) { i = 0; fr = 0.0f; }
+        else if (fl > (float)(n[a] - 2)) { i = n[a] - 2; fr = 1.0f; }
+        else i = (int)fl;
+        i0[a] = i; f[a] = fr;
+    }
+    float v[2][2][2];
+    for (int dx = 0; dx < 2; ++dx)
+        for (int dy = 0; dy < 2; ++dy)
+            for (int dz = 0; dz < 2; ++dz)
+                v[dx][dy][dz] = dist[((size_t)(i0[0] + dx) * ny + (i0[1] + dy)) * nz + (i0[2] + dz)];
+    float c00 = v[0][0][0] * (1 - f[0]) + v[1][0][0] * f[0];
+    float c01 = v[0][0][1] * (1 - f[0]) + v[1][0][1] * f[0];
+    float c10 = v[0][1][0] * (1 - f[0]) + v[1][1][0] * f[0];
+    float c11 = v[0][1][1] * (1 - f[0]) + v[1][1][1] * f[0];
+    float c0 = c00 * (1 - f[1]) + c10 * f[1];
+    float c1 = c01 * (1 - f[1]) + c11 * f[1];
+    out4[0] = c0 * (1 - f[2]) + c1 * f[2];
+    float gx00 = v[1][0][0] - v[0][0][0], gx01 = v[1][0][1] - v[0][0][1];
+    float gx10 = v[1][1][0] - v[0][1][0], gx11 = v[1][1][1] - v[0][1][1];
+    float gx0 = gx00 * (1 - f[1]) + gx10 * f[1];
+    float gx1 = gx01 * (1 - f[1]) + gx11 * f[1];
+    out4[1] = (gx0 * (1 - f[2]) + gx1 * f[2]) * inv_res;
+    float gy0 = c10 - c00, gy1 = c11 - c01;
+    out4[2] = (gy0 * (1 - f[2]) + gy1 * f[2]) * inv_res;
+    out4[3] = (c1 - c0) * inv_res;
+}
+
+void vgo_esdf_query_f32_batch(int nx, int ny, int nz, const double origin[3], double res, const float* dist, int64_t Q,
+                              const float* pts, float* out4) {
+    for (int64_t q = 0; q < Q; ++q) vgo_esdf_query_f32(nx, ny, nz, origin, res, dist, pts + 3 * q, out4 + 4 * q);
+}
+
 void vgo_esdf_query_batch(int nx, int ny, int nz, const double origin[3], double res, const float* dist, int64_t Q,
                           const double* pts, double* out_d, double* out_g) {
     for (int64_t q = 0; q < Q; ++q) vgo_esdf_query(nx, ny, nz, origin, res, dist, pts + 3 * q, out_d + q, out_g + 3 * q);

@@ -158,6 +158,10 @@ int vgo_corridor_check_segment(const vgo_grid_t* g, int deg, const double* coeff
 void vgo_esdf_query(int nx, int ny, int nz, const double origin[3], double res,
                     const float* dist, const double p[3], double* out_d, double out_g[3]);
 
+void vgo_esdf_query_f32(int nx, int ny, int nz, const double origin[3], double res, const float* dist,
+                        const float p[3], float out4[4]);
+void vgo_esdf_query_f32_batch(int nx, int ny, int nz, const double origin[3], double res, const float* dist, int64_t Q,
+                              const float* pts, float* out4);
 void vgo_esdf_query_batch(int nx, int ny, int nz, const double origin[3], double res, const float* dist, int64_t Q,
                           const double* pts, double* out_d, double* out_g);
 

@@ -251,6 +251,22 @@ def esdf_query_batch(dist, origin, res, pts):
     return d, g
 
 
+def esdf_query_f32_batch(dist, origin, res, pts):
+    """oracle fp32 trilinear ESDF over Q float32 points -> float32 [Q,4] = (d, grad)"""
+    ds = np.ascontiguousarray(dist, dtype=np.float32)
+    pt = np.ascontiguousarray(pts, dtype=np.float32)
+    org = _c(origin, np.float64)
+    Q = pt.shape[0]
+    out = np.zeros((Q, 4), dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    O = oracle()
+    O.vgo_esdf_query_f32_batch.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_double, fp, C.c_int64, fp, fp]
+    O.vgo_esdf_query_f32_batch.restype = None
+    O.vgo_esdf_query_f32_batch(ds.shape[0], ds.shape[1], ds.shape[2], _d(org), float(res), ds.ctypes.data_as(fp), Q,
+                               pt.ctypes.data_as(fp), out.ctypes.data_as(fp))
+    return out
+
+
 def make_grid(world):
     """vgo_grid_t over a synth.World (keeps the numpy array alive via the returned tuple)."""
     vox = np.ascontiguousarray(world.voxels, dtype=np.uint8)

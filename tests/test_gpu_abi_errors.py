@@ -190,6 +190,9 @@ def test_bad_arguments_return_codes_and_keep_the_handle_usable(raw):
     assert L.vigo_set_esdf(h, 4, 4, 4, origin, 0.1, NULL) < 0
     assert L.vigo_set_esdf(h, 4, 4, 4, origin, 0.1, dptr(f32)) == 0
     assert L.vigo_esdf_query(h, 4, NULL, dptr(d), dptr(d)) < 0
+    assert L.vigo_esdf_query_f32(h, 4, NULL, dptr(f32)) < 0 and L.vigo_esdf_query_f32(h, 4, dptr(f32), NULL) < 0
+    assert L.vigo_esdf_query_f32(h, -1, dptr(f32), dptr(f32)) < 0
+    assert L.vigo_esdf_query_f32(h, 1, dptr(f32), C.c_void_p(f32.data_ptr() + 4)) < 0           # the 16-byte store needs its alignment
     torch.cuda.synchronize()
     # every refusal left a message, and the handle still works
     assert len(L.vigo_last_error(h)) > 0

@@ -122,6 +122,21 @@ def test_config5_esdf_queries_at_full_size(vigo_handle):
     assert np.isfinite(d_ref).all() and np.isfinite(g_ref).all()
     far = d_ref > 1.0                                    # away from the surfaces the EDT is smooth: |grad| ~ 1
     assert abs(np.median(np.linalg.norm(g_ref[far], axis=1)) - 1.0) < 0.05
+    # the same 1 048 576 queries at the fp32 I/O width of SURVEY.md §8(d) config 5 (12 B in, 16 B out; vigo_esdf_query_f32):
+    # every value and gradient bit for bit against the oracle's fp32 twin, both query orders; and fp32 rounding is all
+    # that separates the two entries
+    p32 = pts.astype(np.float32)
+    ref32 = ol.esdf_query_f32_batch(dist, origin, world.res, p32)
+    got32 = v.esdf_query_f32(to_dev(p32, v.device)).cpu().numpy()
+    assert got32.dtype == np.float32 and np.array_equal(got32.view(np.uint32), ref32.view(np.uint32))
+    got32s = v.esdf_query_f32(to_dev(p32[order], v.device)).cpu().numpy()
+    assert np.array_equal(got32s.view(np.uint32), ref32[order].view(np.uint32))
+    # (the value is continuous across cell borders: every query agrees; the gradient of a trilinear interpolant is not, so
+    # the few points that fp32 rounds into the neighbouring cell see that cell's slope)
+    gdiff = np.abs(got32[:, 1:] - g_ref).max(1)
+    print(f"\nfp32 entry vs fp64 entry: value max diff {np.abs(got32[:, 0] - d_ref).max():.2e}; gradient diff median {np.median(gdiff):.2e}, "
+          f"p99.9 {np.quantile(gdiff, 0.999):.2e}, {(gdiff > 1e-3).sum()} of {Q} queries beyond 1e-3 (cell-border points)")
+    assert np.abs(got32[:, 0] - d_ref).max() < 2e-4 and np.quantile(gdiff, 0.999) < 1e-3 and (gdiff > 1e-3).mean() < 1e-4
 
 
 def test_config5_dynamic_obstacle_term_at_full_size(vigo_handle):
@@ -150,4 +165,5 @@ def test_config5_dynamic_obstacle_term_at_full_size(vigo_handle):
     rel = rel_err_per_traj(got["ctrl"], ref["ctrl"])
     print(f"\nconfig 5a (1024 x 32, 8 obstacles): vs reference-order oracle median {np.median(rel):.2e} p99 {np.quantile(rel, .99):.2e} "
           f"max {rel.max():.2e}; within 1e-4: {(rel <= 1e-4).mean() * 100:.2f} %")
-    assert (rel <= 1e-4).mean() >= 0.995 and np.median(rel) < 1e-8
+    # measured: 100.00 % of the 1024 trajectories inside 1e-4 (worst 2.1e-6) — demanded, not a quantile
+    assert (rel <= 1e-4).all() and np.median(rel) < 1e-8, f"{(rel > 1e-4).sum()} trajectories outside 1e-4, max {rel.max():.3e}"

@@ -222,6 +222,14 @@ def test_esdf_query_ragged_lattices(vigo_handle, shape):
     d, g = v.esdf_query(to_dev(pts, v.device))
     d_ref, g_ref = ol.esdf_query_batch(dist, origin, res, pts)
     assert np.array_equal(d.cpu().numpy(), d_ref) and np.array_equal(g.cpu().numpy(), g_ref)
+    # the fp32 entry on the same lattice: bit for bit against its oracle twin, non-finite and far-away points included
+    p32 = pts.astype(np.float32)
+    p32[60] = (np.nan, 0.0, 0.0)
+    p32[61] = (np.inf, -np.inf, 1e30)
+    p32[62] = (-1e30, 1e-30, 3e38)
+    got = v.esdf_query_f32(to_dev(p32, v.device)).cpu().numpy()
+    ref = ol.esdf_query_f32_batch(dist, origin, res, p32)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
 def test_stale_hip_error_of_another_library_is_not_reported(vigo_handle):

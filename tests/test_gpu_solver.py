@@ -49,7 +49,9 @@ def test_optimize_matches_oracle(vigo_handle, small_world, N, B, n_obs, iters):
     print(f"\n[N={N} B={B} obs={n_obs} it={iters}] vs reference-order oracle: median {np.median(rel):.2e} "
           f"p99 {np.quantile(rel, .99):.2e} max {rel.max():.2e}; status {dict(zip(*np.unique(g['status'], return_counts=True)))}")
     if iters <= 50:
-        assert (rel <= TOL).mean() >= 0.99 and np.median(rel) < 1e-8
+        # measured: EVERY trajectory of every case inside 1e-4 (worst 8.3e-7) — demanded, not a quantile
+        assert (rel <= TOL).all() and np.median(rel) < 1e-8, f"{(rel > TOL).sum()} trajectories outside 1e-4, max {rel.max():.3e}"
+        print(f"    equal status codes: {(g['status'] == ref['status']).mean() * 100:.1f} %")
         assert (g["status"] == ref["status"]).mean() >= 0.97
     else:
         # 200 unconverged iterations amplify a last-bit difference (summation order, pow vs x*x)
@@ -313,16 +315,20 @@ def test_fast_mode_matches_its_emulation_and_the_reference_gate(vigo_handle, sma
     ref = ol.optimize_batch(P, b)
     rel = rel_err_per_traj(r.ctrl.cpu().numpy(), ref["ctrl"])
     print(f"\n[fast N={N}] vs reference-order oracle: median {np.median(rel):.2e} p99 {np.quantile(rel, .99):.2e} max {rel.max():.2e}")
-    assert (rel <= TOL).mean() >= 0.99 and np.median(rel) < 1e-8
+    assert (rel <= TOL).all() and np.median(rel) < 1e-8          # measured: every trajectory, worst 1.1e-6
     v.set_precision(PREC_F64)
 
 
+@pytest.mark.parametrize("mode", ["f64", "f64_fast"])
 @pytest.mark.parametrize("name,n,n_boxes,centre,B,N,start", [("configs[1]", 256, 200, 12.0, 1024, 32, 8.0),
                                                             ("configs[3] shard", 512, 800, 24.0, 8192, 64, 16.0)])
-def test_baseline_sizes_in_full(vigo_handle, name, n, n_boxes, centre, B, N, start):
+def test_baseline_sizes_in_full(vigo_handle, name, n, n_boxes, centre, B, N, start, mode):
     """BASELINE.json configs[1] (1024 x 32, 256^3) and one GPU's shard of configs[3] (8192 x 64, 512^3) at FULL
     size, the bench.py workloads themselves: every trajectory bit-exact vs the emulation-mode oracle and
-    within 1e-4 of the reference-order oracle (the oracle needs ~0.1 s / ~5 s for them)."""
+    within 1e-4 of the reference-order oracle (the oracle needs ~0.1 s / ~5 s for them) — in the reference-order
+    arithmetic (`value` of bench.py) AND in the f64_fast mode bench.py quotes as `other_mode` (explicit fma, one
+    reciprocal per history pair): bit-exact against its own emulation, the same 1e-4 bar on every trajectory."""
+    from trajectory_planner_amd.vigo import PREC_F64, PREC_F64_FAST
     v = vigo_handle
     cfg = 2 if N == 32 else 4
     world = synth.make_box_world(synth.SEED_BASE + cfg, n=n, n_boxes=n_boxes, centre_range=centre)
@@ -335,17 +341,26 @@ def test_baseline_sizes_in_full(vigo_handle, name, n, n_boxes, centre, B, N, sta
     gunk = v.guides_unknown(d["guide_pv"])
     assert np.array_equal(gunk.cpu().numpy(), b.guide_unk)
     d["guide_unk"] = gunk
-    r = v.optimize(**d)
-    g = {k: getattr(r, k).cpu().numpy() for k in ("ctrl", "x", "status", "fx", "iters", "evals")}
-    with emulation(N):
-        e = ol.optimize_batch(P, b)
+    fast = mode == "f64_fast"
+    v.set_precision(PREC_F64_FAST if fast else PREC_F64)
+    try:
+        r = v.optimize(**d)
+        g = {k: getattr(r, k).cpu().numpy() for k in ("ctrl", "x", "status", "fx", "iters", "evals")}
+    finally:
+        v.set_precision(PREC_F64)
+    ol.oracle().vgo_set_emulation_fast(1 if fast else 0)
+    try:
+        with emulation(N):
+            e = ol.optimize_batch(P, b)
+    finally:
+        ol.oracle().vgo_set_emulation_fast(0)
     for k in ("status", "iters", "evals", "x", "ctrl", "fx"):
-        assert np.array_equal(g[k], e[k]), f"{name}: {k} differs from the emulation-mode oracle"
+        assert np.array_equal(g[k], e[k]), f"{name} ({mode}): {k} differs from the emulation-mode oracle"
     ref = ol.optimize_batch(P, b)
     rel = rel_err_per_traj(g["ctrl"], ref["ctrl"])
-    print(f"\n[{name}: {B} x {N}] vs reference-order oracle: median {np.median(rel):.2e} p99 {np.quantile(rel, .99):.2e} "
+    print(f"\n[{name}: {B} x {N}, {mode}] vs reference-order oracle: median {np.median(rel):.2e} p99 {np.quantile(rel, .99):.2e} "
           f"max {rel.max():.2e}; within 1e-4: {(rel <= TOL).mean() * 100:.2f} %")
-    assert (rel <= TOL).all() and np.median(rel) < 1e-8     # 100 % (measured: max 1.2e-6 / 2.1e-6)
+    assert (rel <= TOL).all() and np.median(rel) < 1e-8     # 100 % (measured in f64: max 1.2e-6 / 2.1e-6)
     # fixed boundary control points never move (BT.cpp:690-691)
     assert np.array_equal(g["ctrl"][:, :3], b.ctrl[:, :3]) and np.array_equal(g["ctrl"][:, -3:], b.ctrl[:, -3:])
 

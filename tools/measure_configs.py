@@ -141,6 +141,13 @@ pts_sorted = T(pts.cpu().numpy()[idx])
 dt = timeit(lambda: v.esdf_query(pts_sorted), 50)
 print(json.dumps({"config": "5b: same queries, brick-sorted", "ms": dt * 1e3, "queries_per_s": (1 << 20) / dt,
                   "algorithmic_GBps": (1 << 20) * 60 / dt / 1e9}), flush=True)
+# the same at the fp32 I/O width SURVEY.md §8(d) config 5 states (12 B in, 16 B out): vigo_esdf_query_f32
+out32 = torch.empty(1 << 20, 4, dtype=torch.float32, device=dev)
+for name, p64 in (("uniform random", pts), ("brick-sorted", pts_sorted)):
+    p32 = p64.float().contiguous()
+    dt = timeit(lambda: v.esdf_query_f32(p32, out32), 50)
+    print(json.dumps({"config": f"5b (fp32 I/O): 1M trilinear ESDF queries, {name}", "ms": dt * 1e3, "queries_per_s": (1 << 20) / dt,
+                      "algorithmic_GBps": (1 << 20) * 60 / dt / 1e9, "frac_of_hbm_peak": (1 << 20) * 60 / dt / 8e12}), flush=True)
 v.close()
 
 # config 3: 4096 segments x 10 000 samples corridor check on an occupied/free/unknown map

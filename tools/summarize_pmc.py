@@ -88,7 +88,14 @@ def main():
         merged.update(collect(d, kernel))
     fetch_kib = merged.get("FETCH_SIZE", (0.0, 0))[0]
     write_kib = merged.get("WRITE_SIZE", (0.0, 0))[0]
+    try:    # the library's own identity: content hashes of its sources (include/vigo.h vigo_build_id; loading it starts no GPU work)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from trajectory_planner_amd import _lib
+        build_id = _lib.load().vigo_build_id().decode()
+    except Exception:
+        build_id = None
     res = {
+        "build_id": build_id,
         "build": os.environ.get("VIGO_BUILD", "unrecorded"),   # commit the profiled library was built from (set by the caller)
         "source": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python bench.py (see profiles/README.md); "
                   f"averages over the dispatches of the kernel matching '{kernel}'",

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "vigo_exact_pow_integer": (_d, [_d, _i]),
     "vigo_set_esdf": (_i, [_vp, _i, _i, _i, _d3, _d, _vp]),
     "vigo_esdf_query": (_i, [_vp, _i64, _vp, _vp, _vp]),
+    "vigo_esdf_query_f32": (_i, [_vp, _i64, _vp, _vp]),
 }
 
 _lib = None

@@ -698,4 +698,12 @@ int vigo_esdf_query(vigo_handle_t h, int64_t Q, const double* pts, double* out_d
     return VIGO_OK;
 }
 
+int vigo_esdf_query_f32(vigo_handle_t h, int64_t Q, const float* pts, float* out_dist_grad) {
+    if (!h || Q < 0 || (Q > 0 && (!pts || !out_dist_grad))) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_esdf_query_f32: bad argument");
+    if (Q > 0 && (reinterpret_cast<uintptr_t>(out_dist_grad) & 15u)) return fail(h, VIGO_ERR_INVALID_ARG, "vigo_esdf_query_f32: out must be 16-byte aligned");
+    if (!h->has_esdf) return fail(h, VIGO_ERR_NO_GRID, "vigo_esdf_query_f32 before vigo_set_esdf");
+    VIGO_HIP(h, (hipError_t)vigo::launch_esdf_query_f32(h->stream, h->esdf_view, Q, pts, out_dist_grad));
+    return VIGO_OK;
+}
+
 }  // extern "C"

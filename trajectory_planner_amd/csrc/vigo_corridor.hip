@@ -588,6 +588,69 @@ __global__ void k_esdf_query(EsdfView E, int64_t Q, const double* __restrict__ p
     out_g[q * 3 + 2] = (c1 - c0) / E.res;
 }
 
+// The same query at the I/O width SURVEY.md §8(d) config 5 states for this fp32 lattice: float3 point in, float value +
+// float3 gradient out (12 + 16 B per query instead of 24 + 32), all arithmetic in fp32 on the fp32 corners.  Own
+// definition like the fp64 entry (no reference counterpart); each operation rounded once, in this order
+// (-ffp-contract=off; oracle/vigo_oracle.c vgo_esdf_query_f32 is the same text):
+//   u = (p - (float)origin) * inv_res - 0.5f with inv_res = 1.0f / (float)res computed ONCE on the host,
+//   i = floorf(u) clamped to [0, n - 2] (frac 0 / 1 at the clamps), the trilinear blend x then y then z as above,
+//   gradient differences * inv_res.  The result is ONE 16-byte store {d, gx, gy, gz}.
+struct EsdfF32Const {
+    float origin[3];
+    float inv_res;
+};
+__global__ void k_esdf_query_f32(EsdfView E, EsdfF32Const C, int64_t Q, const float* __restrict__ pts, float4* __restrict__ out) {
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;     // XCD-aware tile map, as above
+    const unsigned base = nb >> 3, rem = nb & 7u;
+    const unsigned tile = xcd * base + (xcd < rem ? xcd : rem) + idx;
+    const int64_t q = (int64_t)tile * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const int n[3] = {E.nx, E.ny, E.nz};
+    int i0[3];
+    float f[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float u = (pts[q * 3 + a] - C.origin[a]) * C.inv_res - 0.5f;
+        const float fl = floorf(u);
+        // (NaN and out-of-range points: the comparisons are made on the float, so the int conversion is never out of range)
+        int i;
+        float fr = u - fl;
+        if (!(fl >= 0.0f)) { i = 0; fr = 0.0f; }
+        else if (fl > (float)(n[a] - 2)) { i = n[a] - 2; fr = 1.0f; }
+        else i = (int)fl;
+        i0[a] = i;
+        f[a] = fr;
+    }
+    const unsigned by = (unsigned)i0[1] / 3u, bz = (unsigned)i0[2] / 3u;
+    const unsigned ly = (unsigned)i0[1] - 3u * by, lz = (unsigned)i0[2] - 3u * bz;
+    const float* cell = E.dist + (((size_t)i0[0] * E.nby + by) * E.nbz + bz) * 32 + (ly * 4 + lz);
+    float v[2][2][2];
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            v[dx][dy][0] = cell[dx * 16 + dy * 4];
+            v[dx][dy][1] = cell[dx * 16 + dy * 4 + 1];
+        }
+    const float c00 = v[0][0][0] * (1 - f[0]) + v[1][0][0] * f[0];
+    const float c01 = v[0][0][1] * (1 - f[0]) + v[1][0][1] * f[0];
+    const float c10 = v[0][1][0] * (1 - f[0]) + v[1][1][0] * f[0];
+    const float c11 = v[0][1][1] * (1 - f[0]) + v[1][1][1] * f[0];
+    const float c0 = c00 * (1 - f[1]) + c10 * f[1];
+    const float c1 = c01 * (1 - f[1]) + c11 * f[1];
+    float4 r;
+    r.x = c0 * (1 - f[2]) + c1 * f[2];
+    const float gx00 = v[1][0][0] - v[0][0][0], gx01 = v[1][0][1] - v[0][0][1];
+    const float gx10 = v[1][1][0] - v[0][1][0], gx11 = v[1][1][1] - v[0][1][1];
+    const float gx0 = gx00 * (1 - f[1]) + gx10 * f[1];
+    const float gx1 = gx01 * (1 - f[1]) + gx11 * f[1];
+    r.y = (gx0 * (1 - f[2]) + gx1 * f[2]) * C.inv_res;
+    const float gy0 = c10 - c00, gy1 = c11 - c01;
+    r.z = (gy0 * (1 - f[2]) + gy1 * f[2]) * C.inv_res;
+    r.w = (c1 - c0) * C.inv_res;
+    out[q] = r;
+}
+
 // one thread per destination float (coalesced writes); values past the lattice edge are zero-filled, never read.
 // Line (x, by, bz) holds the values [x, x + 1] x [3 by, 3 by + 3] x [3 bz, 3 bz + 3], z fastest.
 __global__ void k_esdf_brick(int nx, int ny, int nz, int nby, int nbz, size_t total, const float* __restrict__ src,
@@ -648,6 +711,17 @@ int launch_esdf_query(hipStream_t s, const EsdfView& e, int64_t Q, const double*
     const int block = 256;
     hipLaunchKernelGGL(k_esdf_query, dim3((unsigned)((Q + block - 1) / block)), dim3(block), 0, s, e, Q, pts,
                        out_dist, out_grad);
+    return (int)hipGetLastError();
+}
+
+int launch_esdf_query_f32(hipStream_t s, const EsdfView& e, int64_t Q, const float* pts, float* out4) {
+    if (Q <= 0) return hipSuccess;
+    EsdfF32Const C;
+    for (int a = 0; a < 3; ++a) C.origin[a] = (float)e.origin[a];
+    C.inv_res = 1.0f / (float)e.res;
+    const int block = 256;
+    hipLaunchKernelGGL(k_esdf_query_f32, dim3((unsigned)((Q + block - 1) / block)), dim3(block), 0, s, e, C, Q, pts,
+                       reinterpret_cast<float4*>(out4));
     return (int)hipGetLastError();
 }
 

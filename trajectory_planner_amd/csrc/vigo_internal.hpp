@@ -153,6 +153,8 @@ int launch_check_lists(hipStream_t s, int B, int N, const int32_t* guide_off, in
                        int* bad);
 int launch_esdf_query(hipStream_t s, const EsdfView& e, int64_t Q, const double* pts,
                       double* out_dist, double* out_grad);
+// fp32 I/O and arithmetic: pts float[Q][3], out float[Q][4] = {d, gx, gy, gz} (16-byte aligned)
+int launch_esdf_query_f32(hipStream_t s, const EsdfView& e, int64_t Q, const float* pts, float* out4);
 // row-major [nx][ny][nz] -> the bricked layout of EsdfView
 int launch_esdf_brick(hipStream_t s, int nx, int ny, int nz, const float* src, float* dst);
 // batched B-spline fit (vigo_fit.hip): one-off device factorisation per (K, ts), then the fit

@@ -824,6 +824,14 @@ __device__ __forceinline__ int trial_interval(double& xt, double& xf, double& xd
 #ifndef VIGO_TWOLOOP_MARKSTEIN
 #define VIGO_TWOLOOP_MARKSTEIN 1
 #endif
+// dev switch, measured and left off (profiles/README.md, round 3): 1 = the byte offsets of the 14 ring slots by AGE worked
+// out once per two-loop (14 x {sub, wrap}, pinned in SGPRs) and each of the 28 fetches taking its offset from that table
+// by a static index, instead of a running offset stepped and wrapped before every fetch (4 SALU instructions per fetch).
+// The step loses its 4 SALU instructions and gains 4 s_nop: they had been sitting in the wait states the DPP moves of
+// the butterfly need after the add that feeds them.  +2 % at B = 1024, +3 % on the full-chip batches.
+#ifndef VIGO_RING_TABLE
+#define VIGO_RING_TABLE 0
+#endif
 // dev builds only (-DVIGO_PROFILE_SECTIONS=1, tools/exp_sections.py): shader-clock totals of the sections of an
 // iteration, written over out_x[b][0..9] — never defined in the shipped library
 #ifndef VIGO_PROFILE_SECTIONS
@@ -1195,6 +1203,30 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
                 curB += stepB;
                 if (curB >= kRing * stepB) curB -= kRing * stepB;
             };
+            // (VIGO_RING_TABLE) ringT[i] = byte offset of the pair of age 2 + i
+            int ringT[kRing];
+            if (STEADY && VIGO_RING_TABLE) {
+                int c = curB;
+#pragma unroll
+                for (int i = 0; i < kRing; ++i) {
+                    ringT[i] = c;
+                    // (an opaque SGPR value: otherwise the chain above is re-materialised at every use)
+                    asm volatile("" : "+s"(ringT[i]));
+                    c -= stepB;
+                    if (c < 0) c += kRing * stepB;
+                }
+            }
+            // the pair of age `age` (a literal after unrolling) into a window slot; the running offset (table off) relies
+            // on the two loops asking for the ages in ring order
+            auto ring_fetch_age = [&](int age, bool newer_next, T (&s_)[PPL][3], T (&y_)[PPL][3], YS& ys_) {
+                if (VIGO_RING_TABLE) {
+                    curB = ringT[(age - 2 >= 0 && age - 2 < kRing) ? age - 2 : 0];
+                    ring_fetch(s_, y_, ys_);
+                } else {
+                    ring_fetch(s_, y_, ys_);
+                    if (newer_next) ring_newer(); else ring_older();
+                }
+            };
 #pragma unroll
             for (int q = 0; q < PPL; ++q)
 #pragma unroll
@@ -1204,7 +1236,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
             for (int age = 1; age < kWin; ++age)
                 if (age < bnd) {
                     // (a window of more than two pairs starts with ring slots in it: the ring pointer moves with them)
-                    if (STEADY && age >= 2) { ring_fetch(Ps[age], Py[age], Pys[age]); ring_older(); }
+                    if (STEADY && age >= 2) ring_fetch_age(age, false, Ps[age], Py[age], Pys[age]);
                     else fetch(age, Ps[age], Py[age], Pys[age]);
                 }
 #pragma unroll
@@ -1223,7 +1255,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
                             for (int a = 0; a < 3; ++a) d[q][a] = FAST ? fmaT(na, Py[w][q][a], d[q][a]) : d[q][a] + na * Py[w][q][a];
                     }
                     if (age + kWin < kMaxMem && age + kWin < bnd) {
-                        if (STEADY && age + kWin >= 2) { ring_fetch(Ps[w], Py[w], Pys[w]); ring_older(); }
+                        if (STEADY && age + kWin >= 2) ring_fetch_age(age + kWin, false, Ps[w], Py[w], Pys[w]);
                         else fetch(age + kWin, Ps[w], Py[w], Pys[w]);
                     }
                 }
@@ -1233,8 +1265,10 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
                 // loop starts fetching at age kMaxMem - 1 - kWin.  The compiler must not keep the
                 // first loop's 14 pairs alive in AGPRs for it (24 register moves per pair cost more
                 // VALU slots than three ds_read_b128): LDS is declared clobbered here.
+                if (!VIGO_RING_TABLE) {
 #pragma unroll
-                for (int i = 0; i < kWin + 1; ++i) ring_newer();
+                    for (int i = 0; i < kWin + 1; ++i) ring_newer();
+                }
                 asm volatile("" ::: "memory");
             }
             {
@@ -1260,7 +1294,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
                             for (int a = 0; a < 3; ++a) d[q][a] = FAST ? fmaT(co, Ps[w][q][a], d[q][a]) : d[q][a] + co * Ps[w][q][a];
                     }
                     if (age - kWin >= 0) {
-                        if (STEADY && age - kWin >= 2) { ring_fetch(Ps[w], Py[w], Pys[w]); ring_newer(); }
+                        if (STEADY && age - kWin >= 2) ring_fetch_age(age - kWin, true, Ps[w], Py[w], Pys[w]);
                         else fetch(age - kWin, Ps[w], Py[w], Pys[w]);
                     }
                 }

@@ -1097,10 +1097,96 @@ bool bsplineTraj::optimizeTrajectory() {
     return r.ok;
 }
 
+namespace {
+// A second host thread kept by a caller of makePlanBatch for the batches it splits in two (below): it lives as long as
+// the calling thread, so its HIP stream, staging buffers and worker pool (all thread_local) are created once.
+class Companion {
+public:
+    Companion() : th_([this]() { this->loop(); }) {}
+    ~Companion() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    void start(std::function<void()> job) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = std::move(job);
+            busy_ = true;
+        }
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [this]() { return !busy_; });
+    }
+
+private:
+    void loop() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [this]() { return stop_ || (busy_ && job_); });
+                if (stop_) return;
+                job = std::move(job_);
+                job_ = nullptr;
+            }
+            try { job(); } catch (...) { }      // (makePlanBatch reports failure through its result vector)
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                busy_ = false;
+            }
+            cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool busy_ = false, stop_ = false;
+    std::thread th_;
+};
+std::atomic<size_t> g_pipelineThreshold{2048};
+thread_local bool t_insidePipeline = false;
+}  // namespace
+void bsplineTraj::setBatchPipelineThreshold(size_t planners) { g_pipelineThreshold.store(planners); }
+
 // BT.cpp:333-385 for many planners at once: host prologue per planner, then the rebound loops in
 // lock-step so each optimize() round is one launch over all still-active planners.
 std::vector<bool> bsplineTraj::makePlanBatch(const std::vector<bsplineTraj*>& planners) {
     const size_t P = planners.size();
+    // A large batch runs as TWO pipelined halves, the second on a companion host thread with its own handle and HIP
+    // stream: while one half waits for its device rounds (a chain of single-wave solves, ~10 ms per 1024 planners) the
+    // other half's host work (A*, guide assignment) and device rounds proceed — what a caller otherwise gets only by
+    // planning from two threads of its own.  Planners are independent (per-trajectory results do not depend on which
+    // batch carries them), so the plans are those of the unsplit call.
+    const size_t threshold = g_pipelineThreshold.load();
+    if (!t_insidePipeline && threshold > 0 && P >= threshold && P >= 2) {
+        static thread_local Companion companion;
+        const size_t h = P / 2;
+        const std::vector<bsplineTraj*> first(planners.begin(), planners.begin() + h), second(planners.begin() + h, planners.end());
+        std::vector<bool> r2(second.size(), false);
+        companion.start([&second, &r2]() {
+            t_insidePipeline = true;
+            r2 = bsplineTraj::makePlanBatch(second);
+        });
+        t_insidePipeline = true;
+        std::vector<bool> r1;
+        try {
+            r1 = bsplineTraj::makePlanBatch(first);
+        } catch (...) {
+            t_insidePipeline = false;
+            companion.wait();
+            throw;
+        }
+        t_insidePipeline = false;
+        companion.wait();
+        r1.insert(r1.end(), r2.begin(), r2.end());
+        return r1;
+    }
     std::vector<bool> result(P, false);
     std::vector<Rebound> rb(P);
     std::vector<bsplineTraj*> active;

@@ -273,6 +273,48 @@ int main() {
                         inflight, ms, inflight * NP / (ms * 1e-3), okAll);
             CHECK(eqAll == NP, "concurrent batches give the single-batch control points");
         }
+        // ONE call with 2048 planners: makePlanBatch splits it into two pipelined halves itself (companion host thread, own
+        // handle and stream) — the rate two caller threads got above, from a single call; the same plans as the unsplit call
+        {
+            const int NP2 = 2 * NP;
+            std::vector<nav_msgs::Path> paths2(paths);
+            paths2.insert(paths2.end(), paths.begin(), paths.end());
+            auto construct2 = [&](Run& R) {
+                for (int i = 0; i < NP2; ++i) {
+                    R.owners.emplace_back(new bsplineTraj(makeParams()));
+                    R.owners.back()->setMap(map);
+                    R.owners.back()->updateMaxVel(2.0);
+                    R.owners.back()->updateMaxAcc(3.0);
+                    R.ps.push_back(R.owners.back().get());
+                }
+            };
+            auto plan2 = [&](size_t threshold, Run& R) {
+                bsplineTraj::setBatchPipelineThreshold(threshold);
+                const auto t0 = std::chrono::steady_clock::now();
+                bsplineTraj::updatePathBatch(R.ps, paths2, std::vector<std::vector<Eigen::Vector3d>>(NP2, cond));
+                const auto t1 = std::chrono::steady_clock::now();
+                R.res = bsplineTraj::makePlanBatch(R.ps);
+                const auto t2 = std::chrono::steady_clock::now();
+                bsplineTraj::setBatchPipelineThreshold(2048);
+                R.msU = std::chrono::duration<double, std::milli>(t1 - t0).count();
+                R.msP = std::chrono::duration<double, std::milli>(t2 - t1).count();
+            };
+            Run whole, split;
+            construct2(whole);
+            construct2(split);
+            plan2(0, whole); plan2(0, whole);              // (twice: the first call of this size grows the staging buffers)
+            plan2(2048, split); plan2(2048, split);        // (twice: the first call creates the companion thread's stream and buffers)
+            int same2 = 0, good2 = 0;
+            for (int i = 0; i < NP2; ++i) {
+                const Eigen::MatrixXd a = whole.ps[i]->getControlPoints(), b = split.ps[i]->getControlPoints();
+                same2 += whole.res[i] == split.res[i] && a.cols() == b.cols() && std::memcmp(a.data(), b.data(), sizeof(double) * 3 * a.cols()) == 0 &&
+                         whole.ps[i]->getLastSolverStatus() == split.ps[i]->getLastSolverStatus();
+                good2 += split.res[i];
+            }
+            std::printf("INFO 2048 planners in ONE makePlanBatch call: unsplit %.2f ms (%.0f plans/s), two pipelined halves %.2f ms (%.0f plans/s); updatePathBatch %.2f ms; %d planned, %d of %d identical\n",
+                        whole.msP, NP2 / (whole.msP * 1e-3), split.msP, NP2 / (split.msP * 1e-3), split.msU, good2, same2, NP2);
+            CHECK(same2 == NP2 && good2 >= NP2 * 8 / 10, "makePlanBatch of 2048 planners as two pipelined halves == the unsplit call (control points, success, solver status)");
+        }
     }
 
     // ---- a batch of planners with DIFFERENT yaml values and maps: each is solved with its own parameters (the batch is

@@ -421,3 +421,14 @@ class Vigo:
         self._check(self._lib.vigo_esdf_query(self._h, q, _ptr(pts, torch.float64, "pts", self.device),
                                               C.c_void_p(d.data_ptr()), C.c_void_p(g.data_ptr())), "vigo_esdf_query")
         return d, g
+
+    def esdf_query_f32(self, pts: torch.Tensor, out: Optional[torch.Tensor] = None):
+        """vigo_esdf_query_f32: pts float32 [Q,3] -> float32 [Q,4] = (distance, gradient)"""
+        _shape(pts, (None, 3), "pts")
+        q = pts.shape[0]
+        if out is None:
+            out = torch.empty(q, 4, dtype=torch.float32, device=self.device)
+        _shape(out, (q, 4), "out")
+        self._check(self._lib.vigo_esdf_query_f32(self._h, q, _ptr(pts, torch.float32, "pts", self.device),
+                                                  _ptr(out, torch.float32, "out", self.device)), "vigo_esdf_query_f32")
+        return out
