@@ -441,7 +441,9 @@ def main():
                                           "trajectories_with_guides": share, "max_pairs_per_point": int(len(hist) - 1),
                                           "pairs_per_free_point_histogram": [int(x) for x in hist],
                                           "kernel_ms": kmsp, "value": 1024 * kb * 2 / elp, "unit": "trajectories/s",
-                                          "mean_iters": float(rp.iters.float().mean().item()), "mean_evals": float(rp.evals.float().mean().item())})
+                                          "mean_iters": float(rp.iters.float().mean().item()), "mean_evals": float(rp.evals.float().mean().item()),
+                                          # the launch lasts as long as its slowest wave: the tail of the line-search evaluations
+                                          "max_evals": int(rp.evals.max().item()), "evals_p99": float(torch.quantile(rp.evals.float(), 0.99).item())})
                     if stage < 2:
                         pb = synth.reguide_batch(pw, pb, rp.ctrl.cpu().numpy())
                 rec["kernel_ms"] = rec["stages"][0]["kernel_ms"]

@@ -109,8 +109,8 @@ public:
     static std::vector<bool> makePlanBatch(const std::vector<bsplineTraj*>& planners);
     /* The rebound loop of BT.cpp:611-685 runs on the device between two A* calls (vigo_rebound_rounds, default) or
      * round by round from the host (the round-1 path, kept for comparison: identical control points). */
-    /* makePlanBatch of at least this many planners runs as two pipelined halves (the second on a companion host thread with
-     * its own handle and HIP stream); 0 = never.  Default 2048.  Same plans either way. */
+    /* makePlanBatch of at least this many planners runs as two to four pipelined parts of >= half this size (all but the
+     * first on companion host threads with their own handles and HIP streams); 0 = never.  Default 2048.  Same plans. */
     static void setBatchPipelineThreshold(size_t planners);
     static void setDeviceResidentRebound(bool on);
     static bool deviceResidentRebound();

@@ -1158,34 +1158,43 @@ void bsplineTraj::setBatchPipelineThreshold(size_t planners) { g_pipelineThresho
 // lock-step so each optimize() round is one launch over all still-active planners.
 std::vector<bool> bsplineTraj::makePlanBatch(const std::vector<bsplineTraj*>& planners) {
     const size_t P = planners.size();
-    // A large batch runs as TWO pipelined halves, the second on a companion host thread with its own handle and HIP
-    // stream: while one half waits for its device rounds (a chain of single-wave solves, ~10 ms per 1024 planners) the
-    // other half's host work (A*, guide assignment) and device rounds proceed — what a caller otherwise gets only by
-    // planning from two threads of its own.  Planners are independent (per-trajectory results do not depend on which
-    // batch carries them), so the plans are those of the unsplit call.
+    // A large batch runs as two to four pipelined parts of >= threshold / 2 planners, all but the first on companion
+    // host threads with their own handles and HIP streams: while one part waits for its device rounds (a chain of
+    // single-wave solves, ~10 ms per 1024 planners) the others' host work (A*, guide assignment) and device rounds
+    // proceed — what a caller otherwise gets only by planning from several threads of its own.  Planners are independent
+    // (per-trajectory results do not depend on which batch carries them), so the plans are those of the unsplit call.
     const size_t threshold = g_pipelineThreshold.load();
     if (!t_insidePipeline && threshold > 0 && P >= threshold && P >= 2) {
-        static thread_local Companion companion;
-        const size_t h = P / 2;
-        const std::vector<bsplineTraj*> first(planners.begin(), planners.begin() + h), second(planners.begin() + h, planners.end());
-        std::vector<bool> r2(second.size(), false);
-        companion.start([&second, &r2]() {
-            t_insidePipeline = true;
-            r2 = bsplineTraj::makePlanBatch(second);
-        });
+        constexpr size_t kMaxParts = 4;
+        static thread_local Companion companions[kMaxParts - 1];
+        const size_t per = threshold / 2 > 0 ? threshold / 2 : 1;
+        const size_t parts = std::min(kMaxParts, std::max<size_t>(2, P / per));
+        std::vector<std::vector<bsplineTraj*>> piece(parts);
+        std::vector<std::vector<bool>> res(parts);
+        for (size_t k = 0; k < parts; ++k) {
+            const size_t lo = P * k / parts, hi = P * (k + 1) / parts;
+            piece[k].assign(planners.begin() + lo, planners.begin() + hi);
+            res[k].assign(hi - lo, false);
+        }
+        for (size_t k = 1; k < parts; ++k) {
+            companions[k - 1].start([&piece, &res, k]() {
+                t_insidePipeline = true;
+                res[k] = bsplineTraj::makePlanBatch(piece[k]);
+            });
+        }
         t_insidePipeline = true;
-        std::vector<bool> r1;
         try {
-            r1 = bsplineTraj::makePlanBatch(first);
+            res[0] = bsplineTraj::makePlanBatch(piece[0]);
         } catch (...) {
             t_insidePipeline = false;
-            companion.wait();
+            for (size_t k = 1; k < parts; ++k) companions[k - 1].wait();
             throw;
         }
         t_insidePipeline = false;
-        companion.wait();
-        r1.insert(r1.end(), r2.begin(), r2.end());
-        return r1;
+        for (size_t k = 1; k < parts; ++k) companions[k - 1].wait();
+        std::vector<bool> all;
+        for (size_t k = 0; k < parts; ++k) all.insert(all.end(), res[k].begin(), res[k].end());
+        return all;
     }
     std::vector<bool> result(P, false);
     std::vector<Rebound> rb(P);

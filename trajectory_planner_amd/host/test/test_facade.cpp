@@ -273,12 +273,13 @@ int main() {
                         inflight, ms, inflight * NP / (ms * 1e-3), okAll);
             CHECK(eqAll == NP, "concurrent batches give the single-batch control points");
         }
-        // ONE call with 2048 planners: makePlanBatch splits it into two pipelined halves itself (companion host thread, own
-        // handle and stream) — the rate two caller threads got above, from a single call; the same plans as the unsplit call
-        {
-            const int NP2 = 2 * NP;
-            std::vector<nav_msgs::Path> paths2(paths);
-            paths2.insert(paths2.end(), paths.begin(), paths.end());
+        // ONE call with 2048 / 4096 planners: makePlanBatch splits it into two / four pipelined parts itself (companion host
+        // threads, own handles and streams) — the rate several caller threads got above, from a single call; the same plans
+        // as the unsplit call
+        for (int mult : {2, 4}) {
+            const int NP2 = mult * NP;
+            std::vector<nav_msgs::Path> paths2;
+            for (int k = 0; k < mult; ++k) paths2.insert(paths2.end(), paths.begin(), paths.end());
             auto construct2 = [&](Run& R) {
                 for (int i = 0; i < NP2; ++i) {
                     R.owners.emplace_back(new bsplineTraj(makeParams()));
@@ -299,21 +300,28 @@ int main() {
                 R.msU = std::chrono::duration<double, std::milli>(t1 - t0).count();
                 R.msP = std::chrono::duration<double, std::milli>(t2 - t1).count();
             };
-            Run whole, split;
-            construct2(whole);
-            construct2(split);
-            plan2(0, whole); plan2(0, whole);              // (twice: the first call of this size grows the staging buffers)
-            plan2(2048, split); plan2(2048, split);        // (twice: the first call creates the companion thread's stream and buffers)
+            // (one run alive at a time: a planner owns a 19 MB A* node pool, 4096 of them are 78 GB)
+            struct Kept { std::vector<Eigen::MatrixXd> ctrl; std::vector<int> status; std::vector<bool> res; double msU = 0, msP = 0; };
+            auto runKept = [&](size_t threshold) {
+                Run R;
+                construct2(R);
+                plan2(threshold, R); plan2(threshold, R);      // (twice: the first call of this size grows staging buffers / creates the companions' streams)
+                Kept k;
+                for (int i = 0; i < NP2; ++i) { k.ctrl.push_back(R.ps[i]->getControlPoints()); k.status.push_back(R.ps[i]->getLastSolverStatus()); }
+                k.res = R.res; k.msU = R.msU; k.msP = R.msP;
+                return k;
+            };
+            const Kept whole = runKept(0), split = runKept(2048);
             int same2 = 0, good2 = 0;
             for (int i = 0; i < NP2; ++i) {
-                const Eigen::MatrixXd a = whole.ps[i]->getControlPoints(), b = split.ps[i]->getControlPoints();
+                const Eigen::MatrixXd &a = whole.ctrl[i], &b = split.ctrl[i];
                 same2 += whole.res[i] == split.res[i] && a.cols() == b.cols() && std::memcmp(a.data(), b.data(), sizeof(double) * 3 * a.cols()) == 0 &&
-                         whole.ps[i]->getLastSolverStatus() == split.ps[i]->getLastSolverStatus();
+                         whole.status[i] == split.status[i];
                 good2 += split.res[i];
             }
-            std::printf("INFO 2048 planners in ONE makePlanBatch call: unsplit %.2f ms (%.0f plans/s), two pipelined halves %.2f ms (%.0f plans/s); updatePathBatch %.2f ms; %d planned, %d of %d identical\n",
-                        whole.msP, NP2 / (whole.msP * 1e-3), split.msP, NP2 / (split.msP * 1e-3), split.msU, good2, same2, NP2);
-            CHECK(same2 == NP2 && good2 >= NP2 * 8 / 10, "makePlanBatch of 2048 planners as two pipelined halves == the unsplit call (control points, success, solver status)");
+            std::printf("INFO %d planners in ONE makePlanBatch call: unsplit %.2f ms (%.0f plans/s), %d pipelined parts %.2f ms (%.0f plans/s); updatePathBatch %.2f ms; %d planned, %d of %d identical\n",
+                        NP2, whole.msP, NP2 / (whole.msP * 1e-3), mult, split.msP, NP2 / (split.msP * 1e-3), split.msU, good2, same2, NP2);
+            CHECK(same2 == NP2 && good2 >= NP2 * 8 / 10, "makePlanBatch of 2048 / 4096 planners as pipelined parts == the unsplit call (control points, success, solver status)");
         }
     }
 
