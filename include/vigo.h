@@ -199,6 +199,20 @@ int vigo_cost_grad(vigo_handle_t h, int B, int N, const double* ctrl,
  *   out_fx     double[B] final objective (LB:1328)
  *   out_iters  int32[B]  iteration counter k at exit;  out_evals int32[B] cost evaluations
  *   (any out_* except ctrl may be NULL)
+ *
+ * THE LEVEL RULE (vigo_cost_grad, vigo_optimize, vigo_rebound_rounds; not in the reference).  With plan_in_z = 0 the
+ * z coordinate of a control point feels the smoothness and feasibility terms only (BT.cpp:856-858 zeroes the guide
+ * term's z gradient, BT.cpp:1022 the obstacle term's).  When all N control points of a trajectory lie at one height
+ * — zmax - zmin <= 2^-40 * max(1, |zmin|, |zmax|): a level path as the least-squares fit leaves it — those two z
+ * terms are differences of values that differ by rounding noise; the kernels take them as exactly zero (cost and
+ * gradient), so such a trajectory's z never moves, where the reference lets it drift by that noise (measured:
+ * <= 6e-14 m over 50 iterations).  The deviation is ~12 orders of magnitude inside the 1e-4 parity bar, and exact for
+ * a path that is level to the bit.  What it buys: waves whose trajectories are all level are solved (calls without
+ * obstacles, N <= 64) by an instantiation that carries x and y only — two thirds of the L-BFGS history in LDS, of
+ * every dot product and of the stencils (-8 % at 1024 x 32, -20 % on batches that fill the chip).  The rule is applied
+ * per trajectory, also where a level trajectory shares a wave with one that is not: results never depend on the
+ * batch a trajectory travels in.  The oracle's device-emulation mode applies the same rule; its reference-order mode
+ * restates the reference and does not.
  */
 int vigo_optimize(vigo_handle_t h, int B, int N, double* ctrl,
                   const int32_t* guide_off, const double* guide_pv, const uint8_t* guide_unk,

@@ -221,18 +221,30 @@ static double distance_term(const vigo_params_t* P, int N, const double* c, cons
     return TERM_RESULT();
 }
 
-/* BT.cpp:934-950 */
-static double smoothness_term(int N, const double* c, double* G, double* lanes) {
+/* (device emulation only) THE LEVEL RULE of the kernels (include/vigo.h, vigo_solver.hip set_level): with plan_in_z off and
+ * all N control points at one height to 2^-40 relative, the smoothness and feasibility terms of the z axis — whose
+ * values then differ by rounding noise only — are taken as exactly zero, cost and gradient, so z never moves.  The
+ * reference-order mode knows no such rule: it restates the reference, which lets z drift by that noise. */
+static int traj_level(const vigo_params_t* P, int N, const double* c) {
+    if (!g_emu_group || P->plan_in_z) return 0;
+    double mn = INFINITY, mx = -INFINITY;
+    for (int i = 0; i < N; ++i) { mn = fmin(mn, c[3 * i + 2]); mx = fmax(mx, c[3 * i + 2]); }
+    return (mx - mn) <= 0x1p-40 * fmax(1.0, fmax(fabs(mn), fabs(mx)));
+}
+
+/* BT.cpp:934-950 (axes = 3; 2 under the level rule) */
+static double smoothness_term(int N, const double* c, double* G, double* lanes, int axes) {
     double cost = 0.0;
     for (int i = 0; i < N - 3; ++i) {
         double jk[3], gt[3];
         for (int a = 0; a < 3; ++a) {
             jk[a] = FAST ? fma(3.0, c[3 * (i + 1) + a], fma(-3.0, c[3 * (i + 2) + a], c[3 * (i + 3) + a])) - c[3 * i + a]
                          : ((c[3 * (i + 3) + a] - 3 * c[3 * (i + 2) + a]) + 3 * c[3 * (i + 1) + a]) - c[3 * i + a];
+            if (a >= axes) jk[a] = 0.0;
         }
         LANE_ADD(i, sum3(jk[0] * jk[0], jk[1] * jk[1], jk[2] * jk[2]));
         for (int a = 0; a < 3; ++a) gt[a] = 2.0 * jk[a];
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < axes; ++a) {
             G[3 * i + a] += -gt[a];
             if (FAST) {
                 G[3 * (i + 1) + a] = fma(3.0, gt[a], G[3 * (i + 1) + a]);
@@ -248,13 +260,13 @@ static double smoothness_term(int N, const double* c, double* G, double* lanes) 
 }
 
 /* BT.cpp:952-999; limits hard-coded to 1.0 (BT.cpp:955-956) */
-static double feasibility_term(const vigo_params_t* P, int N, const double* c, double* G, double* lanes) {
+static double feasibility_term(const vigo_params_t* P, int N, const double* c, double* G, double* lanes, int axes) {
     double cost = 0.0;
     const double maxVel = 1.0, maxAcc = 1.0;
     const double ts = P->ts_ctrl;
     double tsInvSqr = 1 / pow(ts, 2);
     for (int i = 0; i < N - 1; ++i) {
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < axes; ++j) {
             double vi = (c[3 * (i + 1) + j] - c[3 * i + j]) / ts;
             if (vi > maxVel) {
                 LANE_ADD(i, P2(vi - maxVel) * tsInvSqr);
@@ -268,7 +280,7 @@ static double feasibility_term(const vigo_params_t* P, int N, const double* c, d
         }
     }
     for (int i = 0; i < N - 2; ++i) {
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < axes; ++j) {
             double ai = (FAST ? fma(-2.0, c[3 * (i + 1) + j], c[3 * (i + 2) + j]) + c[3 * i + j]
                               : (c[3 * (i + 2) + j] - 2 * c[3 * (i + 1) + j]) + c[3 * i + j]) * tsInvSqr;
             if (ai > maxAcc) {
@@ -346,14 +358,16 @@ double vgo_cost_grad(const vigo_params_t* P, int N, const double* ctrl, const in
     double L[4][VGO_MAX_N];   /* per-point cost partials (device emulation) */
     memset(L, 0, sizeof(L));
     const int emu = g_emu_group != 0;
+    const int level = traj_level(P, N, ctrl);
     double cd = distance_term(P, N, ctrl, goff, gpv, gunk, Gd, emu ? L[0] : NULL);
-    double cs = smoothness_term(N, ctrl, Gs, emu ? L[1] : NULL);
-    double cf = feasibility_term(P, N, ctrl, Gf, emu ? L[2] : NULL);
+    double cs = smoothness_term(N, ctrl, Gs, emu ? L[1] : NULL, level ? 2 : 3);
+    double cf = feasibility_term(P, N, ctrl, Gf, emu ? L[2] : NULL, level ? 2 : 3);
     double co = dynamic_term(P, N, ctrl, n_obs, obs, Go, emu ? L[3] : NULL);
     double total = w[0] * cd + w[1] * cs + w[2] * cf + w[3] * co;
     for (int e = 0; e < 3 * N; ++e) {
         double t = FAST ? fma(w[3], Go[e], fma(w[2], Gf[e], fma(w[1], Gs[e], w[0] * Gd[e])))
                         : w[0] * Gd[e] + w[1] * Gs[e] + w[2] * Gf[e] + w[3] * Go[e];
+        if (level && e % 3 == 2) t = 0.0;
         if (grad_full) grad_full[e] = t;
         if (grad_free && e >= 9 && e < 3 * (N - 3)) grad_free[e - 9] = t;
     }

@@ -365,6 +365,73 @@ def test_baseline_sizes_in_full(vigo_handle, name, n, n_boxes, centre, B, N, sta
     assert np.array_equal(g["ctrl"][:, :3], b.ctrl[:, :3]) and np.array_equal(g["ctrl"][:, -3:], b.ctrl[:, -3:])
 
 
+
+@pytest.mark.parametrize("N,B,n_obs,prec", [(32, 301, 0, "f64"), (32, 301, 0, "f64_fast"), (20, 90, 0, "f64"), (64, 75, 0, "f64"), (32, 120, 2, "f64"), (100, 20, 0, "f64")])
+def test_level_rule_on_mixed_batches(vigo_handle, small_world, N, B, n_obs, prec):
+    """THE LEVEL RULE (include/vigo.h): a trajectory whose control points share one height to 2^-40 (and no z planning)
+    keeps its z fixed — the z terms of smoothness and feasibility, rounding noise on such input, are taken as exactly
+    zero — and calls without obstacles solve waves of such trajectories with a kernel that carries x and y only.  Here:
+    batches that MIX exactly level trajectories (z = 1.0 to the bit), level-to-rounding ones (as the fit leaves them) and
+    trajectories with centimetres of vertical jitter, so that level waves, general waves and waves that pair one of
+    each all occur.  (a) every trajectory bit-identical to the emulation-mode oracle, which applies the same rule per
+    trajectory; (b) nothing depends on the pairing: the batch in another order gives the same result per trajectory;
+    (c) against the reference-order oracle, which knows no such rule, every trajectory stays within 1e-4 and a level
+    trajectory's z within 1e-12 of what the reference computes."""
+    from trajectory_planner_amd.vigo import PREC_F64, PREC_F64_FAST
+    v = vigo_handle
+    P = default_params()
+    P.max_iterations = 50
+    v.set_params(P)
+    b = synth.make_bspline_batch(small_world, B, N, 4100 + N + B, start_range=3.0, n_obs=n_obs, z_jitter=0.03, z_share=0.4)
+    spread = np.ptp(b.ctrl[:, :, 2], axis=1)
+    wavy = spread > 1e-6
+    exact = (~wavy) & (np.arange(B) % 3 == 0)
+    b.ctrl[exact, :, 2] = 1.0                                  # exactly level
+    level = ~wavy
+    assert wavy.sum() > B // 5 and level.sum() > B // 5 and exact.sum() > 0 and (level & ~exact).sum() > 0
+    fast = prec == "f64_fast"
+    v.set_precision(PREC_F64_FAST if fast else PREC_F64)
+    ol.oracle().vgo_set_emulation_fast(1 if fast else 0)
+    try:
+        r, d = solve_both(v, P, b)
+        cost, grad, terms = v.cost_grad(**d)
+        with emulation(N):
+            e = ol.optimize_batch(P, b)
+            ce, ge, te = ol.cost_grad_batch(P, b)
+        g = {k: getattr(r, k).cpu().numpy() for k in ("ctrl", "x", "status", "fx", "iters", "evals")}
+        assert np.array_equal(cost.cpu().numpy(), ce) and np.array_equal(grad.cpu().numpy(), ge) and np.array_equal(terms.cpu().numpy(), te)
+        for k in ("status", "iters", "evals", "x", "ctrl", "fx"):
+            assert np.array_equal(g[k], e[k]), f"{k} differs from the emulation-mode oracle"
+        # (b) another order: other neighbours in the wave, other waves level / general
+        perm = np.random.default_rng(N + B).permutation(B)
+        cnt = np.diff(b.guide_off).reshape(B, N)[perm]
+        goff = np.concatenate([[0], np.cumsum(cnt.reshape(-1))]).astype(np.int32)
+        starts = b.guide_off[:-1].reshape(B, N)[perm].reshape(-1)
+        idx = np.concatenate([np.arange(s, s + c) for s, c in zip(starts, cnt.reshape(-1))]) if goff[-1] else np.zeros(0, dtype=np.int64)
+        obs_off = obs = None
+        if b.obs is not None:
+            per = np.diff(b.obs_off)[perm]
+            obs_off = np.concatenate([[0], np.cumsum(per)]).astype(np.int32)
+            obs = np.concatenate([b.obs[b.obs_off[i]:b.obs_off[i + 1]] for i in perm])
+        bp = synth.Batch(np.ascontiguousarray(b.ctrl[perm]), goff, np.ascontiguousarray(b.guide_pv[idx.astype(np.int64)]),
+                         np.ascontiguousarray(b.guide_unk[idx.astype(np.int64)]), obs_off, obs)
+        rp, _ = solve_both(v, P, bp)
+        for k in ("status", "iters", "evals", "x", "ctrl", "fx"):
+            assert np.array_equal(getattr(rp, k).cpu().numpy(), g[k][perm]), f"{k} depends on the order of the batch"
+    finally:
+        v.set_precision(PREC_F64)
+        ol.oracle().vgo_set_emulation_fast(0)
+    # the rule at work: a level trajectory's z has not moved at all, a wavy one's has
+    assert np.array_equal(g["ctrl"][level, :, 2], b.ctrl[level, :, 2])
+    assert (np.abs(g["ctrl"][wavy, 3:-3, 2] - b.ctrl[wavy, 3:-3, 2]).max(1) > 1e-6).all()
+    ref = ol.optimize_batch(P, b)                              # reference order: no level rule
+    rel = rel_err_per_traj(g["ctrl"], ref["ctrl"])
+    zdev = np.abs(g["ctrl"][level, :, 2] - ref["ctrl"][level, :, 2]).max()
+    print(f"\n[level rule N={N} B={B} obs={n_obs} {prec}] level {level.sum()} (exactly {exact.sum()}), wavy {wavy.sum()}; vs reference-order oracle: "
+          f"median {np.median(rel):.2e} max {rel.max():.2e}; largest z difference on a level trajectory {zdev:.2e}")
+    assert (rel <= TOL).all() and zdev < 1e-12
+
+
 def test_parameter_variations_stay_bit_exact(vigo_handle, small_world):
     """Paths of the kernel the default batch does not reach: more obstacles than the LDS cache holds (20 > 16:
     the rest is read from HBM/L2), three or more guide pairs on a control point (beyond the two kept in

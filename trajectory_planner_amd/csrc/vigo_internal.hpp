@@ -54,6 +54,8 @@ struct SolveArgs {
     double* out_fx;
     int32_t* out_iters;
     int32_t* out_evals;
+    // (set by the solve launcher) 1: the waves whose trajectories are all level are solved by a second launch (D = 2)
+    int level_waves_elsewhere;
     // cost_grad outputs
     double* out_cost;
     double* out_grad;

@@ -211,6 +211,33 @@ __device__ __forceinline__ double group_sum1(double v) {
     return a[0];
 }
 
+// min and max of a value over the lanes of a group (the same xor butterfly; order is irrelevant for min / max)
+template <int GROUP>
+__device__ __forceinline__ void group_minmax(double& mn, double& mx) {
+    static_assert(GROUP == 32 || GROUP == 64, "half a wave or a wave");
+    auto step = [&](double omn, double omx) { mn = fmin(mn, omn); mx = fmax(mx, omx); };
+    step(dpp_f64<0xB1>(mn), dpp_f64<0xB1>(mx));
+    step(dpp_f64<0x4E>(mn), dpp_f64<0x4E>(mx));
+    step(dpp_f64<0x141>(mn), dpp_f64<0x141>(mx));
+    step(dpp_f64<0x140>(mn), dpp_f64<0x140>(mx));
+    {
+        double a0, a1, b0, b1;
+        xor16_parts(mn, mn, a0, a1);
+        xor16_parts(mx, mx, b0, b1);
+        mn = fmin(a0, a1);
+        mx = fmax(b0, b1);
+    }
+    if (GROUP == 64) {
+        const int nlo = __double2loint(mn), nhi = __double2hiint(mn), xlo = __double2loint(mx), xhi = __double2hiint(mx);
+        auto l = __builtin_amdgcn_permlane32_swap(nlo, nlo, false, false);
+        auto h = __builtin_amdgcn_permlane32_swap(nhi, nhi, false, false);
+        mn = fmin(__hiloint2double(h[0], l[0]), __hiloint2double(h[1], l[1]));
+        auto l2 = __builtin_amdgcn_permlane32_swap(xlo, xlo, false, false);
+        auto h2 = __builtin_amdgcn_permlane32_swap(xhi, xhi, false, false);
+        mx = fmax(__hiloint2double(h2[0], l2[0]), __hiloint2double(h2[1], l2[1]));
+    }
+}
+
 __device__ __forceinline__ double sum3(double a, double b, double c) { return (a + b) + c; }
 
 // FAST (VIGO_PREC_F64_FAST): explicit fused multiply-adds in the dot products, axpys, stencils
@@ -220,18 +247,24 @@ __device__ __forceinline__ double sum3(double a, double b, double c) { return (a
 __device__ __forceinline__ double fmaT(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fmaT(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-template <bool FAST, typename T>
+// D = the number of leading coordinates that MOVE: 3, or 2 for a level trajectory (see k_optimize): the z components of
+// g, d, s, y are then exactly zero, their products contribute +-0 to every sum and are left out
+template <bool FAST, typename T, int D = 3>
 __device__ __forceinline__ double dot3(const T (&a)[3], const T (&b)[3]) {
+    if (D == 2) {
+        if (FAST) return fmaT((double)a[1], (double)b[1], (double)a[0] * (double)b[0]);
+        return (double)a[0] * (double)b[0] + (double)a[1] * (double)b[1];
+    }
     if (FAST)
         return fmaT((double)a[2], (double)b[2], fmaT((double)a[1], (double)b[1], (double)a[0] * (double)b[0]));
     return sum3((double)a[0] * (double)b[0], (double)a[1] * (double)b[1], (double)a[2] * (double)b[2]);
 }
 // lane partial of a dot product: the lane's first point, then its other points in index order
-template <bool FAST, typename T, int PPL>
+template <bool FAST, typename T, int PPL, int D = 3>
 __device__ __forceinline__ double dot_lane(const T (&a)[PPL][3], const T (&b)[PPL][3]) {
-    double s = dot3<FAST, T>(a[0], b[0]);
+    double s = dot3<FAST, T, D>(a[0], b[0]);
 #pragma unroll
-    for (int q = 1; q < PPL; ++q) s += dot3<FAST, T>(a[q], b[q]);
+    for (int q = 1; q < PPL; ++q) s += dot3<FAST, T, D>(a[q], b[q]);
     return s;
 }
 
@@ -273,10 +306,10 @@ __device__ __forceinline__ double over_ys(double a, const YSv<false>& y, double&
 
 // one L-BFGS history pair of one control point as it sits in LDS (48 B in fp64: three
 // conflict-free ds_read_b128 per lane, one address register)
-template <typename T>
+template <typename T, int D = 3>
 struct alignas(16) HPair {
-    T s[3];
-    T y[3];
+    T s[D];
+    T y[D];
 };
 
 // per-lane view of one trajectory's inputs
@@ -286,6 +319,10 @@ struct LaneProblem {
     static constexpr int kGuideRegs = (PPL == 1) ? 2 : 0;
     static constexpr int kGuideDim = kGuideRegs > 0 ? kGuideRegs : 1;
     int N;
+    // LEVEL RULE (include/vigo.h): plan_in_z off and all N control points at one height to 2^-40 relative — the z
+    // coordinate then feels only the smoothness and feasibility terms of values that differ by rounding noise; those
+    // z terms are taken as exactly zero (cost and gradient), so z never moves.  Group-uniform; set by set_level().
+    bool level;
     int p0;                   // first control point of this lane
     bool has_pt[PPL];         // p0 + q < N
     bool interior[PPL];       // 3 <= p0 + q <= N-4 (a free control point)
@@ -401,7 +438,7 @@ __device__ __forceinline__ void obstacle_term_tab(const DevConst& K, const T (&c
 // (the line search needs g.d after every evaluation, LB:829, and the norms after the last one,
 // LB:1200-1201; fusing them costs three more DPP chains instead of two more reductions).
 // Returns the weighted total cost (group-uniform).
-template <typename T, int GROUP, int PPL, bool FAST, bool OBS = true>
+template <typename T, int GROUP, int PPL, bool FAST, bool OBS = true, int D = 3>
 __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LaneProblem<T, PPL>& Q,
                                                  const T (&c)[PPL][3], const T (&d)[PPL][3], T (&g)[PPL][3],
                                                  double (&sums)[7]) {
@@ -427,6 +464,11 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
         double jj[PPL][3], vv[PPL][3], aa[PPL][3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
+            if (a >= D) {   // a level trajectory: these stencil terms and their gradients are exactly zero (checked at entry)
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) { jj[q][a] = vv[q][a] = aa[q][a] = 0.0; Gs[q][a] = Gf[q][a] = T(0); }
+                continue;
+            }
             T C[PPL], P1[PPL], P2[PPL], P3[PPL];
 #pragma unroll
             for (int q = 0; q < PPL; ++q) C[q] = c[q][a];
@@ -437,14 +479,16 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
                 // smoothness, BT.cpp:934-950
-                const T J0 = FAST ? fmaT(T(3), P1[q], fmaT(T(-3), P2[q], P3[q])) - C[q]
-                                  : ((P3[q] - 3 * P2[q]) + 3 * P1[q]) - C[q];
+                T J0 = FAST ? fmaT(T(3), P1[q], fmaT(T(-3), P2[q], P3[q])) - C[q]
+                            : ((P3[q] - 3 * P2[q]) + 3 * P1[q]) - C[q];
+                if (a == 2 && Q.level) J0 = T(0);                              // level rule: no z terms
                 gt0[q] = T(2.0) * J0;                                          // gradTemp
                 jj[q][a] = (double)(J0 * J0);
                 // feasibility, BT.cpp:952-999 (limits hard-coded to 1.0, :955-956)
-                const T evP = excess((P1[q] - C[q]) / ts);                     // velocity i
-                const T eaP = excess((FAST ? fmaT(T(-2), P1[q], P2[q]) + C[q]
-                                           : (P2[q] - 2 * P1[q]) + C[q]) * tis);   // acceleration i
+                T evP = excess((P1[q] - C[q]) / ts);                           // velocity i
+                T eaP = excess((FAST ? fmaT(T(-2), P1[q], P2[q]) + C[q]
+                                     : (P2[q] - 2 * P1[q]) + C[q]) * tis);     // acceleration i
+                if (a == 2 && Q.level) { evP = T(0); eaP = T(0); }
                 // gradient(j,i+1) += 2(v-vmax)/ts*tsInvSqr, gradient(j,i) += the negation (exactly)
                 gv[q] = (T(2) * evP) / ts * tis;
                 // gradient(j,i), (j,i+2) += 2(a-amax)*tsInvSqr; gradient(j,i+1) += -4(..) = -2x that (exactly)
@@ -560,12 +604,12 @@ __device__ __forceinline__ double eval_cost_grad(const DevConst& K, const LanePr
     for (int q = 0; q < PPL; ++q) {
 #pragma unroll
         for (int a = 0; a < 3; ++a)
-            g[q][a] = !Q.interior[q] ? T(0)
+            g[q][a] = (!Q.interior[q] || a >= D || (a == 2 && Q.level)) ? T(0)
                       : (FAST ? fmaT(w3, Go[q][a], fmaT(w2, Gf[q][a], fmaT(w1, Gs[q][a], w0 * Gd[q][a])))
                               : ((w0 * Gd[q][a] + w1 * Gs[q][a]) + w2 * Gf[q][a]) + w3 * Go[q][a]);
-        const double v4 = dot3<FAST, T>(g[q], d[q]);
-        const double v5 = Q.interior[q] ? dot3<FAST, T>(c[q], c[q]) : 0.0;
-        const double v6 = dot3<FAST, T>(g[q], g[q]);
+        const double v4 = dot3<FAST, T, D>(g[q], d[q]);
+        const double v5 = Q.interior[q] ? dot3<FAST, T>(c[q], c[q]) : 0.0;     // (x.x: the level coordinate counts)
+        const double v6 = dot3<FAST, T, D>(g[q], g[q]);
         if (q == 0) {
             part[0] = pt_d[0]; part[1] = pt_s[0]; part[2] = pt_f[0]; part[3] = pt_o[0];
             part[4] = v4; part[5] = v5; part[6] = v6;
@@ -593,6 +637,7 @@ __device__ __forceinline__ void load_problem(const SolveArgs& A, const DevConst&
     using LP = LaneProblem<T, PPL>;
     const int N = A.N;
     Q.N = N;
+    Q.level = false;
     Q.p0 = lane_in_group * PPL;
     Q.gpv = A.guide_pv;
     Q.gunk = A.guide_unk;
@@ -652,6 +697,18 @@ __device__ __forceinline__ void load_points(const SolveArgs& A, int b, const Lan
     }
 }
 
+// the level rule's test on the control points a group holds (every lane of the group gets the same answer)
+template <typename T, int GROUP, int PPL>
+__device__ __forceinline__ void set_level(const DevConst& K, LaneProblem<T, PPL>& Q, const T (&x)[PPL][3]) {
+    double mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        if (Q.has_pt[q]) { mn = fmin(mn, (double)x[q][2]); mx = fmax(mx, (double)x[q][2]); }
+    }
+    group_minmax<GROUP>(mn, mx);
+    Q.level = !K.plan_in_z && (mx - mn) <= 0x1p-40 * fmax(1.0, fmax(fabs(mn), fabs(mx)));
+}
+
 template <typename T, int PPL>
 __device__ __forceinline__ void store_points(const SolveArgs& A, int b, const LaneProblem<T, PPL>& Q, const T (&x)[PPL][3]) {
 #pragma unroll
@@ -675,6 +732,7 @@ __global__ void __launch_bounds__(kWave) k_cost_grad(SolveArgs A, const DevConst
     load_problem<T, GROUP, PPL>(A, K, b, lane % GROUP, Q);
     T c[PPL][3], g[PPL][3], zero[PPL][3];
     load_points<T, PPL>(A, b, Q, c);
+    set_level<T, GROUP, PPL>(K, Q, c);
 #pragma unroll
     for (int q = 0; q < PPL; ++q) zero[q][0] = zero[q][1] = zero[q][2] = T(0);
     double sums[7];
@@ -857,7 +915,7 @@ __device__ __forceinline__ int trial_interval(double& xt, double& xf, double& xd
 // fp64 at 16 384 x 16 — but costs 6 % when every wave has a SIMD to itself anyway.  Same arithmetic, same bits.
 // OBS == false: the instantiation the launcher picks for calls without an obstacle list (A.obs == nullptr): no staging
 // code, no obstacle loop, six sums per evaluation instead of seven — the same bits, fewer live registers
-template <typename T, int GROUP, int PPL, bool FAST, int WPS = 1, bool OBS = true>
+template <typename T, int GROUP, int PPL, bool FAST, int WPS = 1, bool OBS = true, int D = 3>
 __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevConst* __restrict__ Kp) {
     const DevConst& K = *Kp;  // uniform address: scalar loads at the use sites, not 100+ live SGPRs
     constexpr int TPB = kWave / GROUP;
@@ -872,14 +930,14 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
     // A history slot = its ROWP records followed by the slot's {ys, 1/ys} per trajectory, so the steady-state ring
     // walks ONE byte offset for both (slot stride in bytes, a multiple of 16 for the ds_read_b128s)
     constexpr int kYsSlotBytes = (TPB * (int)sizeof(YS) + 15) & ~15;
-    const int slotB = ROWP * (int)sizeof(HPair<T>) + kYsSlotBytes;
+    const int slotB = ROWP * (int)sizeof(HPair<T, D>) + kYsSlotBytes;
     const int m = K.mem_size;
     // REG1 (one control point per lane): the two newest history pairs (ages 0 and 1) stay in
     // registers, LDS holds the older m - 2 — at N = 64, m = 16 that is 38.3 KB instead of 43.8 KB
     // per wave, i.e. four resident waves per CU (one per SIMD) instead of three.
     constexpr bool REG1 = (PPL == 1);
     const int ms = REG1 ? (m > 2 ? m - 2 : 0) : m;   // history slots in LDS
-    HPair<T>* hist = reinterpret_cast<HPair<T>*>(lds_raw);
+    HPair<T, D>* hist = reinterpret_cast<HPair<T, D>*>(lds_raw);
     double* ys_tab = reinterpret_cast<double*>(lds_raw + (size_t)ms * slotB);   // alphas, obstacle table
 
     const int lane = threadIdx.x;
@@ -894,28 +952,44 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 
     LaneProblem<T, PPL> Q;
     load_problem<T, GROUP, PPL>(A, K, b, lane % GROUP, Q);
+    // x holds this lane's control points: free variables where interior, fixed boundary points
+    // elsewhere (their g, d, s, y are identically zero so they never move).
+    T x[PPL][3];
+    load_points<T, PPL>(A, b, Q, x);
+    set_level<T, GROUP, PPL>(K, Q, x);
+    {
+        // A solve is launched as ONE general kernel (D = 3), or — calls without obstacles, one point per lane — as the
+        // general kernel followed by the D = 2 instantiation, which carries only x and y through the recursion (two
+        // thirds of the history in LDS, of the dot products and of the stencils): a wave whose trajectories are ALL
+        // level is solved by the second launch and skipped by the first, every other wave the other way round.  A
+        // level trajectory that shares a wave with one that is not is solved here with its z terms masked: the same
+        // bits either way, so a result never depends on which trajectory it was paired with.
+        const bool wave_level = __all(Q.level);
+        if (D == 2 && !wave_level) return;
+        if (D == 3 && A.level_waves_elsewhere && wave_level) return;
+    }
 #if VIGO_PROFILE_SECTIONS
     long long tick_ = (long long)__builtin_readcyclecounter();
     double t_eval = 0, t_ls = 0, t_upd = 0, t_two = 0, t_tail = 0, t_pre = 0, t_trial = 0, t_cal = 0;
 #endif
     // history column of each owned point; points that are not free read the zero column and never write
-    HPair<T>* hl[PPL];
+    HPair<T, D>* hl[PPL];
 #pragma unroll
     for (int q = 0; q < PPL; ++q) {
         const int p = Q.p0 + q;
         hl[q] = Q.interior[q] ? hist + (grp * NI + (p - 3)) : hist + ROW;
     }
     for (int slot = lane; slot < ms; slot += kWave) {
-        HPair<T> zero;
+        HPair<T, D> zero;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) zero.s[a] = zero.y[a] = T(0);
-        *reinterpret_cast<HPair<T>*>(lds_raw + (size_t)slot * slotB + (size_t)ROW * sizeof(HPair<T>)) = zero;
+        for (int a = 0; a < D; ++a) zero.s[a] = zero.y[a] = T(0);
+        *reinterpret_cast<HPair<T, D>*>(lds_raw + (size_t)slot * slotB + (size_t)ROW * sizeof(HPair<T, D>)) = zero;
     }
     __syncthreads();   // one wave per workgroup: orders the zero column before the first history read
-    YS* ys_l = reinterpret_cast<YS*>(lds_raw + (size_t)ROWP * sizeof(HPair<T>)) + grp;   // slot 0; slot k at + k * slotB bytes
+    YS* ys_l = reinterpret_cast<YS*>(lds_raw + (size_t)ROWP * sizeof(HPair<T, D>)) + grp;   // slot 0; slot k at + k * slotB bytes
     double* al_l = ys_tab + grp;
-    auto hist_at = [&](int q, int slot) -> HPair<T>& {
-        return *reinterpret_cast<HPair<T>*>(reinterpret_cast<char*>(hl[q]) + (size_t)slot * slotB);
+    auto hist_at = [&](int q, int slot) -> HPair<T, D>& {
+        return *reinterpret_cast<HPair<T, D>*>(reinterpret_cast<char*>(hl[q]) + (size_t)slot * slotB);
     };
     auto ys_at = [&](int slot) -> YS& { return *reinterpret_cast<YS*>(reinterpret_cast<char*>(ys_l) + (size_t)slot * slotB); };
     if (!OBS) { Q.obs = nullptr; Q.o_begin = Q.o_end = 0; }
@@ -948,10 +1022,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
         __syncthreads();  // one wave per workgroup: orders the staging writes before the lanes' reads
     }
 
-    // x holds this lane's control points: free variables where interior, fixed boundary points
-    // elsewhere (their g, d, s, y are identically zero so they never move).
-    T x[PPL][3], g[PPL][3], xp[PPL][3], gp[PPL][3], d[PPL][3];
-    load_points<T, PPL>(A, b, Q, x);
+    T g[PPL][3], xp[PPL][3], gp[PPL][3], d[PPL][3];
 #pragma unroll
     for (int q = 0; q < PPL; ++q)
 #pragma unroll
@@ -981,7 +1052,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
             for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { xp[q][a] = x[q][a]; gp[q][a] = g[q][a]; }  // LB:1172-1173
+                for (int a = 0; a < D; ++a) { xp[q][a] = x[q][a]; gp[q][a] = g[q][a]; }  // LB:1172-1173
             dginit = sums[4];  // g.d for the d just built (reduced at the end of the two-loop below)
             if (step <= 0.) { ls = LBERR_INVALIDPARAMETERS; run = false; }
             else if (0 < dginit) { ls = LBERR_INCREASEGRADIENT; run = false; }
@@ -1013,12 +1084,12 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
                 for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                    for (int a = 0; a < 3; ++a)
+                    for (int a = 0; a < D; ++a)
                         x[q][a] = FAST ? fmaT((T)step, d[q][a], xp[q][a]) : xp[q][a] + (T)step * d[q][a];
             }
 
             VIGO_TICK(t_pre);
-            fx = eval_cost_grad<T, GROUP, PPL, FAST, OBS>(K, Q, x, d, g, sums);  // the only evaluation site (LB:828, :1132)
+            fx = eval_cost_grad<T, GROUP, PPL, FAST, OBS, D>(K, Q, x, d, g, sums);  // the only evaluation site (LB:828, :1132)
             VIGO_TICK(t_eval);
             ++evals;
             if (first) break;
@@ -1071,7 +1142,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
             for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                for (int a = 0; a < 3; ++a) d[q][a] = -g[q][a];  // LB:1144
+                for (int a = 0; a < D; ++a) d[q][a] = -g[q][a];  // LB:1144
             if (xnorm < 1.0) xnorm = 1.0;
             if (gnorm / xnorm <= K.g_epsilon) { ret = LB_ALREADY_MINIMIZED; break; }  // LB:1154-1157
             // d = -g: d.d = g.g and g.d = -(g.g) exactly (negation commutes with every rounding)
@@ -1089,7 +1160,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
             for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { x[q][a] = xp[q][a]; g[q][a] = gp[q][a]; }
+                for (int a = 0; a < D; ++a) { x[q][a] = xp[q][a]; g[q][a] = gp[q][a]; }
             ret = ls;
             break;
         }
@@ -1104,15 +1175,18 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
         for (int q = 0; q < PPL; ++q) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { sv[q][a] = x[q][a] - xp[q][a]; yv[q][a] = g[q][a] - gp[q][a]; }
+            for (int a = 0; a < D; ++a) { sv[q][a] = x[q][a] - xp[q][a]; yv[q][a] = g[q][a] - gp[q][a]; }
             if (!REG1 && Q.interior[q]) {
-                HPair<T> hp;
+                HPair<T, D> hp;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { hp.s[a] = sv[q][a]; hp.y[a] = yv[q][a]; }
+                for (int a = 0; a < D; ++a) { hp.s[a] = sv[q][a]; hp.y[a] = yv[q][a]; }
                 hist_at(q, end) = hp;
             }
         }
-        double ysyy[2] = {dot_lane<FAST, T, PPL>(yv, sv), dot_lane<FAST, T, PPL>(yv, yv)};
+        double ysyy[2] = {dot_lane<FAST, T, PPL, D>(yv, sv), dot_lane<FAST, T, PPL, D>(yv, yv)};
+        // (level trajectory: the z product the general kernel adds here is (+0) * (+0); it turns a lane partial of -0 into
+        // +0, and the sign of a zero ys decides the sign of the infinities the reference then divides into being)
+        if (D == 2) ysyy[0] += 0.0;
         group_sum<GROUP, 2>(ysyy);
         const double ys = ysyy[0], yy = ysyy[1];
         // the two-loop divides by ys of each pair (LB:1300, :1312); FAST keeps its reciprocal instead
@@ -1132,7 +1206,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
         for (int q = 0; q < PPL; ++q)
 #pragma unroll
-            for (int a = 0; a < 3; ++a) d[q][a] = -g[q][a];
+            for (int a = 0; a < D; ++a) d[q][a] = -g[q][a];
 
         constexpr int kWin = VIGO_TWOLOOP_WIN;
         T Ps[kWin][PPL][3], Py[kWin][PPL][3];
@@ -1143,7 +1217,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
                 for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) { s_[q][a] = sv[q][a]; y_[q][a] = yv[q][a]; }
+                    for (int a = 0; a < D; ++a) { s_[q][a] = sv[q][a]; y_[q][a] = yv[q][a]; }
                 ys_ = ys_div;
                 return;
             }
@@ -1151,7 +1225,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
                 for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) { s_[q][a] = s1[q][a]; y_[q][a] = y1[q][a]; }
+                    for (int a = 0; a < D; ++a) { s_[q][a] = s1[q][a]; y_[q][a] = y1[q][a]; }
                 ys_ = ys1;
                 return;
             }
@@ -1159,9 +1233,9 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
             if (slot < 0) slot += ms;
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
-                const HPair<T> h = hist_at(q, slot);
+                const HPair<T, D> h = hist_at(q, slot);
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { s_[q][a] = h.s[a]; y_[q][a] = h.y[a]; }
+                for (int a = 0; a < D; ++a) { s_[q][a] = h.s[a]; y_[q][a] = h.y[a]; }
             }
             ys_ = ys_at(slot);
         };
@@ -1189,9 +1263,9 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
             auto ring_fetch = [&](T (&s_)[PPL][3], T (&y_)[PPL][3], YS& ys_) {
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) {
-                    const HPair<T> h = *reinterpret_cast<const HPair<T>*>(reinterpret_cast<const char*>(hl[q]) + curB);
+                    const HPair<T, D> h = *reinterpret_cast<const HPair<T, D>*>(reinterpret_cast<const char*>(hl[q]) + curB);
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) { s_[q][a] = h.s[a]; y_[q][a] = h.y[a]; }
+                    for (int a = 0; a < D; ++a) { s_[q][a] = h.s[a]; y_[q][a] = h.y[a]; }
                 }
                 ys_ = *reinterpret_cast<const YS*>(reinterpret_cast<const char*>(ys_l) + curB);
             };
@@ -1230,7 +1304,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
             for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { Ps[0][q][a] = sv[q][a]; Py[0][q][a] = yv[q][a]; }
+                for (int a = 0; a < D; ++a) { Ps[0][q][a] = sv[q][a]; Py[0][q][a] = yv[q][a]; }
             Pys[0] = ys_div;
 #pragma unroll
             for (int age = 1; age < kWin; ++age)
@@ -1243,7 +1317,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
             for (int age = 0; age < kMaxMem; ++age) {      // newest -> oldest, LB:1294-1303
                 if (age < bnd) {
                     const int w = age % kWin;
-                    double al = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(Ps[w], d));
+                    double al = group_sum1<GROUP>(dot_lane<FAST, T, PPL, D>(Ps[w], d));
                     al = over_ys<MARK>(al, Pys[w], amin, amax);
                     if (STEADY) al_reg[STEADY ? age : 0] = al;
                     else al_l[age * TPB] = al;         // alpha_j parks in LDS at a static offset
@@ -1252,7 +1326,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
                         for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                            for (int a = 0; a < 3; ++a) d[q][a] = FAST ? fmaT(na, Py[w][q][a], d[q][a]) : d[q][a] + na * Py[w][q][a];
+                            for (int a = 0; a < D; ++a) d[q][a] = FAST ? fmaT(na, Py[w][q][a], d[q][a]) : d[q][a] + na * Py[w][q][a];
                     }
                     if (age + kWin < kMaxMem && age + kWin < bnd) {
                         if (STEADY && age + kWin >= 2) ring_fetch_age(age + kWin, false, Ps[w], Py[w], Pys[w]);
@@ -1276,14 +1350,14 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
                 for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) d[q][a] *= sc;
+                    for (int a = 0; a < D; ++a) d[q][a] *= sc;
             }
             // the window now holds the ages [max(0, bound - kWin), bound)
 #pragma unroll
             for (int age = kMaxMem - 1; age >= 0; --age) {  // oldest -> newest, LB:1307-1316
                 if (age < bnd) {
                     const int w = age % kWin;
-                    double beta = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(Py[w], d));
+                    double beta = group_sum1<GROUP>(dot_lane<FAST, T, PPL, D>(Py[w], d));
                     beta = over_ys<MARK>(beta, Pys[w], amin, amax);
                     const double cod = (STEADY ? al_reg[STEADY ? age : 0] : al_l[age * TPB]) - beta;
                     {
@@ -1291,7 +1365,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
                         for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                            for (int a = 0; a < 3; ++a) d[q][a] = FAST ? fmaT(co, Ps[w][q][a], d[q][a]) : d[q][a] + co * Ps[w][q][a];
+                            for (int a = 0; a < D; ++a) d[q][a] = FAST ? fmaT(co, Ps[w][q][a], d[q][a]) : d[q][a] + co * Ps[w][q][a];
                     }
                     if (age - kWin >= 0) {
                         if (STEADY && age - kWin >= 2) ring_fetch_age(age - kWin, true, Ps[w], Py[w], Pys[w]);
@@ -1304,7 +1378,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
             for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                for (int a = 0; a < 3; ++a) bad |= !(d[q][a] == d[q][a]);
+                for (int a = 0; a < D; ++a) bad |= !(d[q][a] == d[q][a]);
             return bad;
         };
         VIGO_TICK(t_upd);
@@ -1316,7 +1390,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
                 for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) d[q][a] = -g[q][a];
+                    for (int a = 0; a < D; ++a) d[q][a] = -g[q][a];
                 two_loop(std::false_type{});
             }
         } else {
@@ -1329,7 +1403,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
         for (int q = 0; q < PPL; ++q)
 #pragma unroll
-            for (int a = 0; a < 3; ++a) d[q][a] = Q.interior[q] ? d[q][a] : T(0);
+            for (int a = 0; a < D; ++a) d[q][a] = Q.interior[q] ? d[q][a] : T(0);
         VIGO_TICK(t_two);
         if (REG1) {
             // the age-1 pair turns age 2 for the next two-loop: it leaves the registers for the LDS
@@ -1338,9 +1412,9 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) {
                     if (Q.interior[q]) {
-                        HPair<T> hp;
+                        HPair<T, D> hp;
 #pragma unroll
-                        for (int a = 0; a < 3; ++a) { hp.s[a] = s1[q][a]; hp.y[a] = y1[q][a]; }
+                        for (int a = 0; a < D; ++a) { hp.s[a] = s1[q][a]; hp.y[a] = y1[q][a]; }
                         hist_at(q, end) = hp;
                     }
                 }
@@ -1351,10 +1425,10 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 #pragma unroll
             for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { s1[q][a] = sv[q][a]; y1[q][a] = yv[q][a]; }
+                for (int a = 0; a < D; ++a) { s1[q][a] = sv[q][a]; y1[q][a] = yv[q][a]; }
             ys1 = ys_div;
         }
-        sums[4] = group_sum1<GROUP>(dot_lane<FAST, T, PPL>(g, d));  // dginit of the next line search (LB:746)
+        sums[4] = group_sum1<GROUP>(dot_lane<FAST, T, PPL, D>(g, d));  // dginit of the next line search (LB:746)
         step = 1.0;  // LB:1321
         VIGO_TICK(t_tail);
         VIGO_TICK(t_cal);    // back-to-back: the cost of one probe
@@ -1384,12 +1458,12 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
     }
 }
 
-template <typename T, int GROUP, bool FAST>
+template <typename T, int GROUP, bool FAST, int D = 3>
 size_t optimize_lds_bytes(int N, int m, int ppl, bool with_obstacles) {
     const int TPB = kWave / GROUP;
     const int ms = ppl == 1 ? (m > 2 ? m - 2 : 0) : m;   // REG1: ages 0 and 1 live in registers
     // per slot: one record per free control point + the zero column, then {ys, 1/ys} per trajectory (see k_optimize)
-    const size_t slot = ((size_t)TPB * (N - 6) + 1) * sizeof(HPair<T>) + (((size_t)TPB * sizeof(YSv<FAST>) + 15) & ~(size_t)15);
+    const size_t slot = ((size_t)TPB * (N - 6) + 1) * sizeof(HPair<T, D>) + (((size_t)TPB * sizeof(YSv<FAST>) + 15) & ~(size_t)15);
     size_t h = (size_t)ms * slot;
     h += (size_t)m * TPB * sizeof(double);        // the alphas of the general two-loop
     if (with_obstacles) h += (size_t)TPB * kObsTabDoubles<GROUP> * sizeof(double);
@@ -1482,28 +1556,50 @@ static int raise_dynamic_lds(LaunchState& L, int slot, KernelT kernel) {
     return (int)hipSuccess;
 }
 
+// dev switch: 0 = never launch the level (D = 2) instantiation
+#ifndef VIGO_LEVEL_KERNEL
+#define VIGO_LEVEL_KERNEL 1
+#endif
 template <typename T, int GROUP, int PPL, bool FAST, bool OBS>
-static int launch_optimize_t(hipStream_t s, const SolveArgs& a, const DevConst& k, const DevConst* kd, LaunchState& L) {
+static int launch_optimize_t(hipStream_t s, const SolveArgs& a_in, const DevConst& k, const DevConst* kd, LaunchState& L) {
     const int tpb = kWave / GROUP;
-    const size_t lds = optimize_lds_bytes<T, GROUP, FAST>(a.N, k.mem_size, PPL, a.obs != nullptr);
-    if (lds > kLdsPerWorkgroup) return (int)hipErrorInvalidValue;  // refused earlier by vigo_optimize
+    SolveArgs a = a_in;
     dim3 grid((a.B + tpb - 1) / tpb), block(kWave);
-    // slot = arithmetic (fp32 / fp64 / fp64 fast) x shape (GROUP, PPL) x waves per SIMD x with / without obstacles
+    // slot = arithmetic (fp32 / fp64 / fp64 fast) x shape (GROUP, PPL) x waves per SIMD x with / without obstacles;
+    // the level instantiations (one point per lane, no obstacles) follow from 48 on
     const int arith = std::is_same<T, float>::value ? 0 : (FAST ? 2 : 1);
     const int shape = GROUP == 32 ? 0 : (PPL == 1 ? 1 : (PPL == 2 ? 2 : 3));
     const int slot = (arith * 4 + shape) * 4;
     // a solver wavefront per SIMD (4 per CU) is full occupancy for these kernels; unknown SIMD count: never switch
     const int simds = L.simd_count > 0 ? L.simd_count : (1 << 30);
-    auto go = [&](auto kernel, int sl) -> int {
+    auto go = [&](auto kernel, int sl, size_t lds) -> int {
         int e = raise_dynamic_lds(L, sl, kernel);
         if (e != (int)hipSuccess) return e;
         hipLaunchKernelGGL(kernel, grid, block, lds, s, a, kd);
         return (int)hipGetLastError();
     };
-    if constexpr (PPL == 1) if ((int)grid.x > simds && lds <= kLdsPerWorkgroup / 8) {   // more waves than SIMDs and 8 fit a CU: two per SIMD
-        return go(&k_optimize<T, GROUP, PPL, FAST, 2, OBS>, slot + (OBS ? 1 : 3));
+    // Calls that can hold level trajectories (no z planning) and have an instantiation for them are two launches: the
+    // general kernel, whose waves of level trajectories exit at once, then the level kernel, whose other waves do.
+    constexpr bool kHasLevel = VIGO_LEVEL_KERNEL && PPL == 1 && !OBS;
+    const bool two = kHasLevel && !k.plan_in_z;
+    a.level_waves_elsewhere = two ? 1 : 0;
+    const size_t lds = optimize_lds_bytes<T, GROUP, FAST, 3>(a.N, k.mem_size, PPL, a.obs != nullptr);
+    if (lds > kLdsPerWorkgroup) return (int)hipErrorInvalidValue;  // refused earlier by vigo_optimize
+    int e;
+    if (PPL == 1 && (int)grid.x > simds && lds <= kLdsPerWorkgroup / 8) {   // more waves than SIMDs and 8 fit a CU: two per SIMD
+        if constexpr (PPL == 1) e = go(&k_optimize<T, GROUP, PPL, FAST, 2, OBS, 3>, slot + (OBS ? 1 : 3), lds);
+        else e = (int)hipErrorInvalidValue;
+    } else {
+        e = go(&k_optimize<T, GROUP, PPL, FAST, 1, OBS, 3>, slot + (OBS ? 0 : 2), lds);
     }
-    return go(&k_optimize<T, GROUP, PPL, FAST, 1, OBS>, slot + (OBS ? 0 : 2));
+    if (e != (int)hipSuccess || !two) return e;
+    if constexpr (kHasLevel) {
+        const size_t lds2 = optimize_lds_bytes<T, GROUP, FAST, 2>(a.N, k.mem_size, PPL, false);
+        const int slot2 = 48 + arith * 4 + shape * 2;
+        if ((int)grid.x > simds && lds2 <= kLdsPerWorkgroup / 8) return go(&k_optimize<T, GROUP, PPL, FAST, 2, OBS, 2>, slot2 + 1, lds2);
+        return go(&k_optimize<T, GROUP, PPL, FAST, 1, OBS, 2>, slot2, lds2);
+    }
+    return e;
 }
 
 template <typename T, bool FAST, bool OBS>

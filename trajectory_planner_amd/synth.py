@@ -121,9 +121,11 @@ def lookup(world: World, pts: np.ndarray, bit: int) -> np.ndarray:
 
 
 def make_bspline_batch(world: World, B: int, N: int, seed: int, start_range: float = 8.0, jitter: float = 0.05,
-                       n_obs: int = 0, guide2_prob: float = 0.3) -> Batch:
+                       n_obs: int = 0, guide2_prob: float = 0.3, z_jitter: float = 0.0, z_share: float = 0.5) -> Batch:
     """Straight 0.25 m-spaced paths with lateral jitter, fitted to N control points; guide pairs
-    for the free control points that start inside an inflated obstacle."""
+    for the free control points that start inside an inflated obstacle.  z_jitter > 0: a share
+    z_share of the trajectories (chosen by a second generator, so the rest of the batch is unchanged) also gets
+    vertical jitter N(0, z_jitter^2) per path point — trajectories that are NOT level (the kernels' level rule)."""
     rng = np.random.default_rng(seed)
     K = N - 2
     start = np.concatenate([rng.uniform(-start_range, start_range, size=(B, 2)), np.full((B, 1), 1.0)], axis=1)
@@ -133,6 +135,10 @@ def make_bspline_batch(world: World, B: int, N: int, seed: int, start_range: flo
     s = np.arange(K) * CTRL_SPACING
     pts = start[:, None, :] + s[None, :, None] * dirv[:, None, :]
     pts = pts + rng.normal(0.0, jitter, size=(B, K, 1)) * lat[:, None, :]
+    if z_jitter > 0.0:
+        rz = np.random.default_rng(seed + 77)
+        wavy = rz.random(B) < z_share
+        pts[:, :, 2] += rz.normal(0.0, z_jitter, size=(B, K)) * wavy[:, None]
     ctrl = fit_control_points(pts, CTRL_TS)
 
     # guide pairs: p = c + (penetration + 0.3) * u, v = u (bsplineTraj.cpp:532: direction points
