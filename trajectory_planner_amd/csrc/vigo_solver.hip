@@ -10,6 +10,9 @@
 //     initial control points and the result only.
 //   * every scalar of the More-Thuente search is replicated across the group's lanes; the two
 //     groups of a wave diverge freely (exec masking), all cross-lane traffic stays inside a group.
+//   * a trajectory whose control points all lie at one height (and no z planning) cannot move in z by more than
+//     rounding noise: the LEVEL RULE (include/vigo.h) holds its z fixed, and waves of such trajectories run the
+//     D = 2 instantiation of the solve kernel, which carries x and y only — 2/3 of the history, dots and stencils.
 //   * per-trajectory sums (cost terms, dot products) are: a per-point partial, the lane's
 //     points added in index order, then a butterfly all-reduce inside the group,
 //     v += lane[i ^ m], m = 1,2,..,GROUP/2 — a fixed tree, so results are deterministic and
@@ -1637,7 +1640,9 @@ int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, const 
     // Measured (tools/exp_solver.py, VIGO_EXP_MATRIX=1: N = 16 ... 200 x the three arithmetic modes): the instantiation
     // without obstacle code is 4 - 18 % faster everywhere except f64_fast at 32 < N <= 64 on batches with more waves
     // than SIMDs (8 % slower there): those keep the general kernel, which treats a missing list as no obstacles.
-    if (precision == VIGO_PREC_F64_FAST && a.N > 32 && a.N <= 64 && L.simd_count > 0 && a.B > L.simd_count)
+    // (Only where the level instantiation cannot apply — z planning on: with it, level waves go to the D = 2 kernel, 20 %
+    // faster than either, and the corner is not worth keeping them from it.)
+    if (precision == VIGO_PREC_F64_FAST && a.N > 32 && a.N <= 64 && L.simd_count > 0 && a.B > L.simd_count && (k.plan_in_z || !VIGO_LEVEL_KERNEL))
         return launch_optimize_with_obstacles(s, a, k, kd, precision, L);
     return launch_optimize_o<false>(s, a, k, kd, precision, L);
 }
