@@ -225,8 +225,13 @@ static double distance_term(const vigo_params_t* P, int N, const double* c, cons
  * all N control points at one height to 2^-40 relative, the smoothness and feasibility terms of the z axis — whose
  * values then differ by rounding noise only — are taken as exactly zero, cost and gradient, so z never moves.  The
  * reference-order mode knows no such rule: it restates the reference, which lets z drift by that noise. */
+/* the kernels decide ONCE per solve, from the control points the solve starts with (a trajectory just outside the band
+ * that the smoothing pulls into it later stays a general one to the end): vgo_optimize pins the answer here for its
+ * evaluations; -1 = decide from the points given (the standalone cost / gradient) */
+static int g_level_pinned = -1;
 static int traj_level(const vigo_params_t* P, int N, const double* c) {
     if (!g_emu_group || P->plan_in_z) return 0;
+    if (g_level_pinned >= 0) return g_level_pinned;
     double mn = INFINITY, mx = -INFINITY;
     for (int i = 0; i < N; ++i) { mn = fmin(mn, c[3 * i + 2]); mx = fmax(mx, c[3 * i + 2]); }
     return (mx - mn) <= 0x1p-40 * fmax(1.0, fmax(fabs(mn), fabs(mx)));
@@ -766,7 +771,9 @@ int vgo_optimize(const vigo_params_t* P, int N, double* ctrl, const int32_t* gof
     double x[3 * VGO_MAX_N];
     memcpy(x, ctrl + 9, sizeof(double) * n);
     solve_ctx S = {P, N, ctrl, goff, gpv, gunk, n_obs, obs, w};
+    g_level_pinned = traj_level(P, N, ctrl);      /* (device emulation) the level rule's decision for this solve */
     int ret = vgo_lbfgs(n, x, fx_out, solve_eval, &S, P, iters, evals, NULL, NULL);
+    g_level_pinned = -1;
     if (x_out) memcpy(x_out, x, sizeof(double) * n);
     return ret;
 }

@@ -27,7 +27,18 @@ for case in range(cases):
     n_obs = int(rng.choice([0, 0, 1, 3, 17]))
     P.pred_horizon = float(rng.choice([2.0, 2.0, 0.5, 3.0, 12.0]))   # 11 / 3 / 16 / 61 predicted steps per obstacle
     fast = bool(rng.integers(0, 2))
-    b = synth.make_bspline_batch(world, B, N, int(rng.integers(1 << 30)), start_range=3.0, n_obs=n_obs)
+    # level trajectories, trajectories with vertical jitter, or both in one batch (the level rule and its D = 2 kernel);
+    # some of the level ones level to the bit, some with a vertical offset of a few ulps (inside / around the 2^-40 band)
+    zj = float(rng.choice([0.0, 0.0, 0.03]))
+    b = synth.make_bspline_batch(world, B, N, int(rng.integers(1 << 30)), start_range=3.0, n_obs=n_obs, z_jitter=zj,
+                                 z_share=float(rng.choice([0.3, 0.5, 1.0])))
+    for i in range(B):
+        kind = int(rng.integers(0, 4))
+        if np.ptp(b.ctrl[i, :, 2]) < 1e-6:
+            if kind == 0:
+                b.ctrl[i, :, 2] = float(rng.choice([1.0, 0.0, -2.5, 1e-300, 1234.5]))
+            elif kind == 1:
+                b.ctrl[i, int(rng.integers(0, N)), 2] += float(rng.choice([1e-13, 5e-13, 9.0e-13, 9.2e-13, 2e-12, 1e-9]))
     w = np.ones((B, 4)) * rng.choice([1.0, 2.0, 4.0], size=(B, 4))
     v = Vigo(0, P, 2 if fast else 0)
     v.set_grid(torch.from_numpy(world.voxels).cuda(), world.origin, world.res)
@@ -47,6 +58,18 @@ for case in range(cases):
     ok = ok and np.array_equal(c.cpu().numpy(), ce, equal_nan=True) and np.array_equal(g.cpu().numpy(), ge, equal_nan=True)
     if not ok:
         bad += 1
+        if bad <= int(os.environ.get("VIGO_FUZZ_DETAIL", "0")):
+            for k in ("status", "iters", "evals", "fx", "x", "ctrl"):
+                a, bb = getattr(r, k).cpu().numpy(), e[k]
+                rows = np.nonzero(~np.isclose(a, bb, rtol=0, atol=0, equal_nan=True).reshape(B, -1).all(1))[0]
+                print("   ", k, "differs in trajectories", rows.tolist()[:12], flush=True)
+            zs = b.ctrl[:, :, 2]
+            print("    z spread per trajectory", np.ptp(zs, axis=1).tolist(), "z0", zs[:, 0].tolist(), flush=True)
+            print("    cost equal", np.array_equal(c.cpu().numpy(), ce, equal_nan=True), "grad equal", np.array_equal(g.cpu().numpy(), ge, equal_nan=True), flush=True)
+            a, bb = r.ctrl.cpu().numpy(), e["ctrl"]
+            i = int(np.nonzero(~(a == bb).reshape(B, -1).all(1))[0][0]) if not np.array_equal(a, bb, equal_nan=True) else 0
+            print("    first differing trajectory", i, "status gpu/oracle", int(r.status[i]), int(e["status"][i]), "iters", int(r.iters[i]), int(e["iters"][i]),
+                  "evals", int(r.evals[i]), int(e["evals"][i]), "max |diff| ctrl", float(np.nanmax(np.abs(a[i] - bb[i]))), "fx", float(r.fx[i]), float(e["fx"][i]), flush=True)
         print(json.dumps({"MISMATCH": case, "N": N, "B": B, "m": int(P.mem_size), "it": int(P.max_iterations), "obs": n_obs, "fast": fast,
                           "geps": float(P.g_epsilon), "ls": int(P.max_linesearch), "z": int(P.plan_in_z)}), flush=True)
     v.close()

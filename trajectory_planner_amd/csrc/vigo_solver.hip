@@ -962,9 +962,9 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
     set_level<T, GROUP, PPL>(K, Q, x);
     {
         // A solve is launched as ONE general kernel (D = 3), or — calls without obstacles, one point per lane — as the
-        // general kernel followed by the D = 2 instantiation, which carries only x and y through the recursion (two
-        // thirds of the history in LDS, of the dot products and of the stencils): a wave whose trajectories are ALL
-        // level is solved by the second launch and skipped by the first, every other wave the other way round.  A
+        // D = 2 instantiation, which carries only x and y through the recursion (two thirds of the history in LDS, of
+        // the dot products and of the stencils), followed by the general kernel: a wave whose trajectories are ALL
+        // level is solved by the first launch and skipped by the second, every other wave the other way round.  A
         // level trajectory that shares a wave with one that is not is solved here with its z terms masked: the same
         // bits either way, so a result never depends on which trajectory it was paired with.
         const bool wave_level = __all(Q.level);
@@ -1581,26 +1581,31 @@ static int launch_optimize_t(hipStream_t s, const SolveArgs& a_in, const DevCons
         hipLaunchKernelGGL(kernel, grid, block, lds, s, a, kd);
         return (int)hipGetLastError();
     };
-    // Calls that can hold level trajectories (no z planning) and have an instantiation for them are two launches: the
-    // general kernel, whose waves of level trajectories exit at once, then the level kernel, whose other waves do.
+    // Calls that can hold level trajectories (no z planning) and have an instantiation for them are two launches: FIRST the
+    // level kernel, whose waves with a trajectory that is not level exit at once, THEN the general kernel, whose waves
+    // of level trajectories do.  The order matters: each launch decides from the control points it finds; a level
+    // trajectory's z is untouched by the first launch, so the second still sees it level and skips it — the other way
+    // round, a trajectory just outside the band that the general solve smooths into it would be solved a second time.
     constexpr bool kHasLevel = VIGO_LEVEL_KERNEL && PPL == 1 && !OBS;
     const bool two = kHasLevel && !k.plan_in_z;
     a.level_waves_elsewhere = two ? 1 : 0;
     const size_t lds = optimize_lds_bytes<T, GROUP, FAST, 3>(a.N, k.mem_size, PPL, a.obs != nullptr);
     if (lds > kLdsPerWorkgroup) return (int)hipErrorInvalidValue;  // refused earlier by vigo_optimize
-    int e;
+    int e = (int)hipSuccess;
+    if constexpr (kHasLevel) {
+        if (two) {
+            const size_t lds2 = optimize_lds_bytes<T, GROUP, FAST, 2>(a.N, k.mem_size, PPL, false);
+            const int slot2 = 48 + arith * 4 + shape * 2;
+            if ((int)grid.x > simds && lds2 <= kLdsPerWorkgroup / 8) e = go(&k_optimize<T, GROUP, PPL, FAST, 2, OBS, 2>, slot2 + 1, lds2);
+            else e = go(&k_optimize<T, GROUP, PPL, FAST, 1, OBS, 2>, slot2, lds2);
+            if (e != (int)hipSuccess) return e;
+        }
+    }
     if (PPL == 1 && (int)grid.x > simds && lds <= kLdsPerWorkgroup / 8) {   // more waves than SIMDs and 8 fit a CU: two per SIMD
         if constexpr (PPL == 1) e = go(&k_optimize<T, GROUP, PPL, FAST, 2, OBS, 3>, slot + (OBS ? 1 : 3), lds);
         else e = (int)hipErrorInvalidValue;
     } else {
         e = go(&k_optimize<T, GROUP, PPL, FAST, 1, OBS, 3>, slot + (OBS ? 0 : 2), lds);
-    }
-    if (e != (int)hipSuccess || !two) return e;
-    if constexpr (kHasLevel) {
-        const size_t lds2 = optimize_lds_bytes<T, GROUP, FAST, 2>(a.N, k.mem_size, PPL, false);
-        const int slot2 = 48 + arith * 4 + shape * 2;
-        if ((int)grid.x > simds && lds2 <= kLdsPerWorkgroup / 8) return go(&k_optimize<T, GROUP, PPL, FAST, 2, OBS, 2>, slot2 + 1, lds2);
-        return go(&k_optimize<T, GROUP, PPL, FAST, 1, OBS, 2>, slot2, lds2);
     }
     return e;
 }
