@@ -91,6 +91,15 @@ def algorithmic_bytes(n, m, iters, evals, gpairs, elem=8):
     return elem * (4 * n * ramp + 12 * n * iters.astype(np.int64) + evals.astype(np.int64) * (7 * n + 7 * gpairs))
 
 
+def level_count(batch):
+    """trajectories the kernels' level rule applies to (plan_in_z off in every bench configuration): all control points at one
+    height to 2^-40 relative — the synthetic paths of SURVEY.md §8(d) fly at z = 1.0"""
+    import numpy as np
+    z = batch.ctrl[:, :, 2]
+    zmin, zmax = z.min(1), z.max(1)
+    return int(((zmax - zmin) <= 2.0 ** -40 * np.maximum(1.0, np.maximum(np.abs(zmin), np.abs(zmax)))).sum())
+
+
 def cpu_baseline(args, seconds, threads):
     """time the CPU oracle (reference order) on repeats of the config batch; returns traj/s"""
     import numpy as np
@@ -537,7 +546,9 @@ def main():
             "config": {"workload": wname, "trajs_per_gpu": B, "ctrl_pts": N, "lbfgs_iters": args.iters,
                        "mem_size": int(P.mem_size), "g_epsilon": float(P.g_epsilon), "grid": list(dims),
                        "guide_pairs_per_gpu": int(gpv.shape[0]), "sharding": f"batch-dp{world_size}, no data-path collective",
-                       "mean_iters": float(iters.mean()), "mean_evals": float(evals.mean())},
+                       "mean_iters": float(iters.mean()), "mean_evals": float(evals.mean()),
+                       # how many of the batch's trajectories the level rule (include/vigo.h) applies to: those run the D = 2 kernel
+                       "level_trajectories_per_gpu": int(level_count(batch))},
             "map_bcast_ms": bcast_ms,
             "map_snapshot_identical_on_all_ranks": snapshot_ok,
             "collectives": None if not use_dist else {

@@ -149,6 +149,13 @@ for case in range(cases):
         if not (dq[i] == dd.value and np.array_equal(gq[i], gg)):
             fail(case, "esdf_query", i=i, dims=ed)
             break
+    # the fp32-I/O entry on the same lattice, bit for bit against its oracle twin (non-finite points included)
+    ep32 = ep.astype(np.float32)
+    ep32[:3] = [(np.nan, 0, 0), (np.inf, -np.inf, 1e30), (-3e38, 1e-30, 0)]
+    got32 = v.esdf_query_f32(to_dev(ep32, v.device)).cpu().numpy()
+    ref32 = ol.esdf_query_f32_batch(dist, eo, res, ep32)
+    if not np.array_equal(got32.view(np.uint32), ref32.view(np.uint32)):
+        fail(case, "esdf_query_f32", dims=ed)
     v.close()
     if (case + 1) % 10 == 0:
         print(f"{case + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
