@@ -260,31 +260,46 @@ def test_fp32_mode_cost_and_statistics(vigo_handle, small_world):
     v.set_precision(PREC_F64)
 
 
-@pytest.mark.parametrize("N,B,prec", [(32, 4100, PREC_F32), (64, 2100, PREC_F32), (16, 4100, PREC_F64), (20, 4100, 2)])
-def test_large_batches_use_the_two_wave_kernel_with_identical_results(vigo_handle, small_world, N, B, prec):
+@pytest.mark.parametrize("N,B,prec,n_obs", [(32, 4100, PREC_F32, 1), (64, 2100, PREC_F32, 1), (16, 4100, PREC_F64, 1), (20, 4100, 2, 1),
+                                            (32, 4100, PREC_F32, 0), (64, 2100, PREC_F32, 0), (16, 4100, PREC_F64, 0), (20, 4100, 2, 0)])
+def test_large_batches_use_the_two_wave_kernel_with_identical_results(vigo_handle, small_world, N, B, prec, n_obs):
     """Batches with more wavefronts than the chip has SIMDs whose history leaves room for eight waves per CU (fp32
     state, or short fp64 trajectories) run the register-capped instantiation (two waves per SIMD, scratch
     spills): the same arithmetic — every trajectory bit-identical to the same batch solved in slices small
-    enough for the one-wave instantiation."""
+    enough for the one-wave instantiation.  Without obstacles the batch (level trajectories with some vertically
+    jittered ones among them) goes through the register-capped LEVEL instantiation and the general one."""
     v = vigo_handle
     P = default_params()
     P.max_iterations = 30
     v.set_params(P)
     v.set_precision(prec)
-    b = synth.make_bspline_batch(small_world, B, N, 1234 + N, start_range=3.0, n_obs=1)
+    b = synth.make_bspline_batch(small_world, B, N, 1234 + N, start_range=3.0, n_obs=n_obs, z_jitter=0.0 if n_obs else 0.02, z_share=0.1)
     d = batch_to_dev(b, v.device)
     full = v.optimize(**d)
     step = 500
     for lo in range(0, B, step):
         hi = min(B, lo + step)
         goff = b.guide_off[lo * N:hi * N + 1]
-        ooff = b.obs_off[lo:hi + 1]
-        sl = synth.Batch(b.ctrl[lo:hi], goff - goff[0], b.guide_pv[goff[0]:goff[-1]], b.guide_unk[goff[0]:goff[-1]],
-                         ooff - ooff[0], b.obs[ooff[0]:ooff[-1]])
+        ooff = obs = None
+        if n_obs:
+            ooff = b.obs_off[lo:hi + 1]
+            obs = b.obs[ooff[0]:ooff[-1]]
+            ooff = ooff - ooff[0]
+        sl = synth.Batch(b.ctrl[lo:hi], goff - goff[0], b.guide_pv[goff[0]:goff[-1]], b.guide_unk[goff[0]:goff[-1]], ooff, obs)
         part = v.optimize(**batch_to_dev(sl, v.device))
         for k in ("ctrl", "x", "status", "fx", "iters", "evals"):
             assert torch.equal(getattr(part, k), getattr(full, k)[lo:hi]), (k, lo)
     assert bool(torch.isfinite(full.ctrl).all())
+    if prec != PREC_F32 and not n_obs:       # and against the emulation oracle (which has no fp32 mode)
+        fast = prec == 2
+        ol.oracle().vgo_set_emulation_fast(1 if fast else 0)
+        try:
+            with emulation(N):
+                e = ol.optimize_batch(P, b)
+        finally:
+            ol.oracle().vgo_set_emulation_fast(0)
+        for k in ("status", "iters", "evals", "x", "ctrl", "fx"):
+            assert np.array_equal(getattr(full, k).cpu().numpy(), e[k]), f"{k} differs from the emulation-mode oracle"
     v.set_precision(PREC_F64)
 
 
