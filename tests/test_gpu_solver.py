@@ -260,9 +260,15 @@ def test_fp32_mode_cost_and_statistics(vigo_handle, small_world):
     v.set_precision(PREC_F64)
 
 
-@pytest.mark.parametrize("N,B,prec,n_obs", [(32, 4100, PREC_F32, 1), (64, 2100, PREC_F32, 1), (16, 4100, PREC_F64, 1), (20, 4100, 2, 1),
-                                            (32, 4100, PREC_F32, 0), (64, 2100, PREC_F32, 0), (16, 4100, PREC_F64, 0), (20, 4100, 2, 0)])
-def test_large_batches_use_the_two_wave_kernel_with_identical_results(vigo_handle, small_world, N, B, prec, n_obs):
+@pytest.mark.parametrize("N,B,prec,n_obs,mem,iters", [
+    (32, 4100, PREC_F32, 1, 16, 30), (64, 2100, PREC_F32, 1, 16, 30), (16, 4100, PREC_F64, 1, 16, 30), (20, 4100, 2, 1, 16, 30),
+    (32, 4100, PREC_F32, 0, 16, 30), (64, 2100, PREC_F32, 0, 16, 30), (16, 4100, PREC_F64, 0, 16, 30), (20, 4100, 2, 0, 16, 30),
+    # fp64 at 21 < N <= 64 without obstacles: the level instantiations that keep 4 / 5 history pairs in registers (eight
+    # waves per CU) — full history (the steady-state two-loop after the 16th iteration) and a history of 15 (the general
+    # two-loop throughout, ring of 10 / 9 slots)
+    (32, 4200, PREC_F64, 0, 16, 40), (32, 4200, 2, 0, 16, 40), (32, 2300, PREC_F64, 0, 15, 30), (64, 2100, PREC_F64, 0, 16, 40),
+    (50, 1300, 2, 0, 16, 30), (64, 1300, PREC_F64, 0, 15, 25)])
+def test_large_batches_use_the_two_wave_kernel_with_identical_results(vigo_handle, small_world, N, B, prec, n_obs, mem, iters):
     """Batches with more wavefronts than the chip has SIMDs whose history leaves room for eight waves per CU (fp32
     state, or short fp64 trajectories) run the register-capped instantiation (two waves per SIMD, scratch
     spills): the same arithmetic — every trajectory bit-identical to the same batch solved in slices small
@@ -270,7 +276,8 @@ def test_large_batches_use_the_two_wave_kernel_with_identical_results(vigo_handl
     jittered ones among them) goes through the register-capped LEVEL instantiation and the general one."""
     v = vigo_handle
     P = default_params()
-    P.max_iterations = 30
+    P.max_iterations = iters
+    P.mem_size = mem
     v.set_params(P)
     v.set_precision(prec)
     b = synth.make_bspline_batch(small_world, B, N, 1234 + N, start_range=3.0, n_obs=n_obs, z_jitter=0.0 if n_obs else 0.02, z_share=0.1)

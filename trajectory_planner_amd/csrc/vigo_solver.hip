@@ -918,8 +918,12 @@ __device__ __forceinline__ int trial_interval(double& xt, double& xf, double& xd
 // fp64 at 16 384 x 16 — but costs 6 % when every wave has a SIMD to itself anyway.  Same arithmetic, same bits.
 // OBS == false: the instantiation the launcher picks for calls without an obstacle list (A.obs == nullptr): no staging
 // code, no obstacle loop, six sums per evaluation instead of seven — the same bits, fewer live registers
-template <typename T, int GROUP, int PPL, bool FAST, int WPS = 1, bool OBS = true, int D = 3>
+// RH = history pairs besides the newest that stay in registers (ages 1 .. RH; 0 for more than one point per lane: all in
+// LDS): 1 normally; 4 or 5 in the level instantiations launched on batches that fill the chip (VIGO_LEVEL_RH below):
+// fewer ring slots in LDS are more resident waves per CU
+template <typename T, int GROUP, int PPL, bool FAST, int WPS = 1, bool OBS = true, int D = 3, int RH = (PPL == 1 ? 1 : 0)>
 __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevConst* __restrict__ Kp) {
+    static_assert(PPL == 1 ? (RH >= 1 && RH <= 6) : RH == 0, "register-held history only with one point per lane");
     const DevConst& K = *Kp;  // uniform address: scalar loads at the use sites, not 100+ live SGPRs
     constexpr int TPB = kWave / GROUP;
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -939,7 +943,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
     // registers, LDS holds the older m - 2 — at N = 64, m = 16 that is 38.3 KB instead of 43.8 KB
     // per wave, i.e. four resident waves per CU (one per SIMD) instead of three.
     constexpr bool REG1 = (PPL == 1);
-    const int ms = REG1 ? (m > 2 ? m - 2 : 0) : m;   // history slots in LDS
+    const int ms = REG1 ? (m > RH + 1 ? m - (RH + 1) : 0) : m;   // history slots in LDS
     HPair<T, D>* hist = reinterpret_cast<HPair<T, D>*>(lds_raw);
     double* ys_tab = reinterpret_cast<double*>(lds_raw + (size_t)ms * slotB);   // alphas, obstacle table
 
@@ -1030,12 +1034,15 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
     for (int q = 0; q < PPL; ++q)
 #pragma unroll
         for (int a = 0; a < 3; ++a) g[q][a] = xp[q][a] = gp[q][a] = d[q][a] = T(0);
-    T s1[PPL][3], y1[PPL][3];   // REG1: the age-1 pair of the next two-loop
-    YS ys1{};
+    constexpr int kRH = RH > 0 ? RH : 1;
+    T sR[kRH][PPL][3], yR[kRH][PPL][3];   // REG1: the pairs of ages 1 .. RH of the next two-loop (sR[j] = age j + 1)
+    YS ysR[kRH]{};
 #pragma unroll
     for (int q = 0; q < PPL; ++q)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) s1[q][a] = y1[q][a] = T(0);
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int j = 0; j < kRH; ++j) sR[j][q][a] = yR[j][q][a] = T(0);
     double sums[7];
     int evals = 0;
     int ret = LBERR_UNKNOWN;
@@ -1195,14 +1202,14 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
         // the two-loop divides by ys of each pair (LB:1300, :1312); FAST keeps its reciprocal instead
         const YS ys_div = make_ys(ys, static_cast<YS*>(nullptr));
         if (!REG1) ys_at(end) = ys_div;
-        const bool have1 = REG1 && k >= 2;   // s1/y1 hold the previous iteration's pair (age 1 now)
+        const bool haveR = REG1 && k >= RH + 1;   // sR[RH - 1] holds a pair (age RH now): it moves to the LDS ring below
 
         // two-loop recursion, LB:1286-1316, fully unrolled over the pair's age with a register
         // window of kWin pairs (static index age % kWin): the pair needed kWin steps ahead is
         // fetched from LDS into the window slot the current step has just consumed, so the
         // dependent chain never waits for LDS and does no address arithmetic or copies.
         const int bound = (m <= k) ? m : k;
-        // !REG1: slot of the pair just stored (age 0); REG1: slot of the age-2 pair (last one written)
+        // !REG1: slot of the pair just stored (age 0); REG1: slot of the pair of age RH + 1 (the last one written)
         const int newest = REG1 ? last : end;
         if (!REG1) end = (end + 1 == m) ? 0 : end + 1;
         ++k;
@@ -1224,15 +1231,16 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
                 ys_ = ys_div;
                 return;
             }
-            if (REG1 && age == 1) {
+            if (REG1 && age >= 1 && age <= RH) {
+                const int j = (age - 1 < kRH && age >= 1) ? age - 1 : 0;
 #pragma unroll
                 for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                    for (int a = 0; a < D; ++a) { s_[q][a] = s1[q][a]; y_[q][a] = y1[q][a]; }
-                ys_ = ys1;
+                    for (int a = 0; a < D; ++a) { s_[q][a] = sR[j][q][a]; y_[q][a] = yR[j][q][a]; }
+                ys_ = ysR[j];
                 return;
             }
-            int slot = REG1 ? newest - (age - 2) : newest - age;
+            int slot = REG1 ? newest - (age - (RH + 1)) : newest - age;
             if (slot < 0) slot += ms;
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
@@ -1254,15 +1262,16 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
             // through an SGPR — `age < bnd` becomes a scalar branch instead of a compare + exec-mask block per step)
             const int bnd = STEADY ? kMaxMem : __builtin_amdgcn_readfirstlane(bound);
             double al_reg[STEADY ? kMaxMem : 1];
-            // STEADY: the LDS ring (kMaxMem - 2 slots) is walked with running byte offsets — one
+            // STEADY: the LDS ring (kMaxMem - RH - 1 slots) is walked with running byte offsets — one
             // add and a wrap per fetch instead of slot arithmetic and two quarter-rate multiplies
-            constexpr int kRing = kMaxMem - 2;
+            constexpr int kRing = kMaxMem - (RH + 1);
+            constexpr int kFirstRing = RH + 1;    // the youngest age that lives in the ring
             const int stepB = slotB;
             // (the slot index is the same in every live lane — all trajectories of a wave are in the
             // same iteration — and is taken through an SGPR so the ring walk is scalar work; the caller
             // checks the uniformity)
             const int lastU = STEADY ? __builtin_amdgcn_readfirstlane(last) : 0;
-            int curB = lastU * stepB;   // slot of the age-2 pair
+            int curB = lastU * stepB;   // slot of the pair of age RH + 1
             auto ring_fetch = [&](T (&s_)[PPL][3], T (&y_)[PPL][3], YS& ys_) {
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) {
@@ -1280,7 +1289,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
                 curB += stepB;
                 if (curB >= kRing * stepB) curB -= kRing * stepB;
             };
-            // (VIGO_RING_TABLE) ringT[i] = byte offset of the pair of age 2 + i
+            // (VIGO_RING_TABLE) ringT[i] = byte offset of the pair of age RH + 1 + i
             int ringT[kRing];
             if (STEADY && VIGO_RING_TABLE) {
                 int c = curB;
@@ -1297,7 +1306,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
             // on the two loops asking for the ages in ring order
             auto ring_fetch_age = [&](int age, bool newer_next, T (&s_)[PPL][3], T (&y_)[PPL][3], YS& ys_) {
                 if (VIGO_RING_TABLE) {
-                    curB = ringT[(age - 2 >= 0 && age - 2 < kRing) ? age - 2 : 0];
+                    curB = ringT[(age - kFirstRing >= 0 && age - kFirstRing < kRing) ? age - kFirstRing : 0];
                     ring_fetch(s_, y_, ys_);
                 } else {
                     ring_fetch(s_, y_, ys_);
@@ -1313,7 +1322,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
             for (int age = 1; age < kWin; ++age)
                 if (age < bnd) {
                     // (a window of more than two pairs starts with ring slots in it: the ring pointer moves with them)
-                    if (STEADY && age >= 2) ring_fetch_age(age, false, Ps[age], Py[age], Pys[age]);
+                    if (STEADY && age >= kFirstRing) ring_fetch_age(age, false, Ps[age], Py[age], Pys[age]);
                     else fetch(age, Ps[age], Py[age], Pys[age]);
                 }
 #pragma unroll
@@ -1332,13 +1341,13 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
                             for (int a = 0; a < D; ++a) d[q][a] = FAST ? fmaT(na, Py[w][q][a], d[q][a]) : d[q][a] + na * Py[w][q][a];
                     }
                     if (age + kWin < kMaxMem && age + kWin < bnd) {
-                        if (STEADY && age + kWin >= 2) ring_fetch_age(age + kWin, false, Ps[w], Py[w], Pys[w]);
+                        if (STEADY && age + kWin >= kFirstRing) ring_fetch_age(age + kWin, false, Ps[w], Py[w], Pys[w]);
                         else fetch(age + kWin, Ps[w], Py[w], Pys[w]);
                     }
                 }
             }
             if (STEADY) {
-                // the ring pointer has gone once around (age kMaxMem == age 2's slot); the second
+                // the ring pointer has gone once around (age kMaxMem == the slot of age RH + 1); the second
                 // loop starts fetching at age kMaxMem - 1 - kWin.  The compiler must not keep the
                 // first loop's 14 pairs alive in AGPRs for it (24 register moves per pair cost more
                 // VALU slots than three ds_read_b128): LDS is declared clobbered here.
@@ -1371,7 +1380,7 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
                             for (int a = 0; a < D; ++a) d[q][a] = FAST ? fmaT(co, Ps[w][q][a], d[q][a]) : d[q][a] + co * Ps[w][q][a];
                     }
                     if (age - kWin >= 0) {
-                        if (STEADY && age - kWin >= 2) ring_fetch_age(age - kWin, true, Ps[w], Py[w], Pys[w]);
+                        if (STEADY && age - kWin >= kFirstRing) ring_fetch_age(age - kWin, true, Ps[w], Py[w], Pys[w]);
                         else fetch(age - kWin, Ps[w], Py[w], Pys[w]);
                     }
                 }
@@ -1409,27 +1418,35 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
             for (int a = 0; a < D; ++a) d[q][a] = Q.interior[q] ? d[q][a] : T(0);
         VIGO_TICK(t_two);
         if (REG1) {
-            // the age-1 pair turns age 2 for the next two-loop: it leaves the registers for the LDS
-            // ring (overwriting the pair that would be age m), the new pair takes its place
-            if (have1 && ms > 0) {
+            // the pair of age RH turns age RH + 1 for the next two-loop: it leaves the registers for the LDS
+            // ring (overwriting the pair that would be age m); the younger ones move up by one, the new pair is age 1
+            if (haveR && ms > 0) {
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) {
                     if (Q.interior[q]) {
                         HPair<T, D> hp;
 #pragma unroll
-                        for (int a = 0; a < D; ++a) { hp.s[a] = s1[q][a]; hp.y[a] = y1[q][a]; }
+                        for (int a = 0; a < D; ++a) { hp.s[a] = sR[kRH - 1][q][a]; hp.y[a] = yR[kRH - 1][q][a]; }
                         hist_at(q, end) = hp;
                     }
                 }
-                ys_at(end) = ys1;
+                ys_at(end) = ysR[kRH - 1];
                 last = end;
                 end = (end + 1 == ms) ? 0 : end + 1;
             }
 #pragma unroll
+            for (int j = kRH - 1; j > 0; --j) {
+#pragma unroll
+                for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                    for (int a = 0; a < D; ++a) { sR[j][q][a] = sR[j - 1][q][a]; yR[j][q][a] = yR[j - 1][q][a]; }
+                ysR[j] = ysR[j - 1];
+            }
+#pragma unroll
             for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                for (int a = 0; a < D; ++a) { s1[q][a] = sv[q][a]; y1[q][a] = yv[q][a]; }
-            ys1 = ys_div;
+                for (int a = 0; a < D; ++a) { sR[0][q][a] = sv[q][a]; yR[0][q][a] = yv[q][a]; }
+            ysR[0] = ys_div;
         }
         sums[4] = group_sum1<GROUP>(dot_lane<FAST, T, PPL, D>(g, d));  // dginit of the next line search (LB:746)
         step = 1.0;  // LB:1321
@@ -1462,9 +1479,9 @@ __global__ void __launch_bounds__(kWave, WPS) k_optimize(SolveArgs A, const DevC
 }
 
 template <typename T, int GROUP, bool FAST, int D = 3>
-size_t optimize_lds_bytes(int N, int m, int ppl, bool with_obstacles) {
+size_t optimize_lds_bytes(int N, int m, int ppl, bool with_obstacles, int rh = 1) {
     const int TPB = kWave / GROUP;
-    const int ms = ppl == 1 ? (m > 2 ? m - 2 : 0) : m;   // REG1: ages 0 and 1 live in registers
+    const int ms = ppl == 1 ? (m > rh + 1 ? m - (rh + 1) : 0) : m;   // REG1: ages 0 .. rh live in registers
     // per slot: one record per free control point + the zero column, then {ys, 1/ys} per trajectory (see k_optimize)
     const size_t slot = ((size_t)TPB * (N - 6) + 1) * sizeof(HPair<T, D>) + (((size_t)TPB * sizeof(YSv<FAST>) + 15) & ~(size_t)15);
     size_t h = (size_t)ms * slot;
@@ -1563,6 +1580,17 @@ static int raise_dynamic_lds(LaunchState& L, int slot, KernelT kernel) {
 #ifndef VIGO_LEVEL_KERNEL
 #define VIGO_LEVEL_KERNEL 1
 #endif
+// History pairs besides the newest that the level kernel keeps in registers on batches with more waves than SIMDs
+// (1 = as everywhere), where LDS decides how many waves a CU holds.  N <= 32 (two trajectories per wave): 4 pairs,
+// 24.4 -> 19.3 KB, six -> EIGHT waves per CU (256 VGPRs, no spills): 1.74 -> 1.47 ms at 16 384 x 32 (2 pairs: 1.60,
+// 3: 1.61, 5: 1.54).  32 < N <= 64 (one per wave): 5 pairs, 26.8 -> 19.2 KB, six -> eight: 1.85 -> 1.54 ms at 8192 x 64
+// (4 pairs, seven waves: 1.71; 6 pairs: 1.57).  Same arithmetic, same bits.
+#ifndef VIGO_LEVEL_RH
+#define VIGO_LEVEL_RH 4
+#endif
+#ifndef VIGO_LEVEL_RH64
+#define VIGO_LEVEL_RH64 5
+#endif
 template <typename T, int GROUP, int PPL, bool FAST, bool OBS>
 static int launch_optimize_t(hipStream_t s, const SolveArgs& a_in, const DevConst& k, const DevConst* kd, LaunchState& L) {
     const int tpb = kWave / GROUP;
@@ -1596,8 +1624,24 @@ static int launch_optimize_t(hipStream_t s, const SolveArgs& a_in, const DevCons
         if (two) {
             const size_t lds2 = optimize_lds_bytes<T, GROUP, FAST, 2>(a.N, k.mem_size, PPL, false);
             const int slot2 = 48 + arith * 4 + shape * 2;
-            if ((int)grid.x > simds && lds2 <= kLdsPerWorkgroup / 8) e = go(&k_optimize<T, GROUP, PPL, FAST, 2, OBS, 2>, slot2 + 1, lds2);
-            else e = go(&k_optimize<T, GROUP, PPL, FAST, 1, OBS, 2>, slot2, lds2);
+            // fp64, two trajectories per wave, more waves than SIMDs: keep VIGO_LEVEL_RH pairs besides the newest in
+            // registers when that buys a further resident wave per CU (N = 32, m = 16: 24.4 -> 22.7 KB, six -> seven)
+            constexpr int kRH = GROUP == 32 ? VIGO_LEVEL_RH : VIGO_LEVEL_RH64;
+            constexpr bool kHasRH = std::is_same<T, double>::value && kRH > 1;
+            bool done = false;
+            if constexpr (kHasRH) {
+                const size_t lds3 = optimize_lds_bytes<T, GROUP, FAST, 2>(a.N, k.mem_size, PPL, false, kRH);
+                if ((int)grid.x > simds && lds2 > kLdsPerWorkgroup / 8 && kLdsPerWorkgroup / lds3 > kLdsPerWorkgroup / lds2) {
+                    // (more than four waves per CU put two on a SIMD: the register-capped build, 256 VGPRs)
+                    constexpr int kWps = kRH >= 4 ? 2 : 1;
+                    e = go(&k_optimize<T, GROUP, PPL, FAST, kWps, OBS, 2, kRH>, 60 + (FAST ? 1 : 0) + (GROUP == 64 ? 2 : 0), lds3);
+                    done = true;
+                }
+            }
+            if (!done) {
+                if ((int)grid.x > simds && lds2 <= kLdsPerWorkgroup / 8) e = go(&k_optimize<T, GROUP, PPL, FAST, 2, OBS, 2>, slot2 + 1, lds2);
+                else e = go(&k_optimize<T, GROUP, PPL, FAST, 1, OBS, 2>, slot2, lds2);
+            }
             if (e != (int)hipSuccess) return e;
         }
     }
