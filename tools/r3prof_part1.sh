@@ -2,7 +2,7 @@ set -o pipefail
 export TMPDIR=/tmp
 # the level instantiation (last template argument D = 2) does the work on these batches; the general one, launched before it,
 # exits at once on level waves and is listed in the kernel-stats files
-export KERNEL_FILTER=', 2>(vigo::SolveArgs'
+export KERNEL_FILTER=', false, 2, '
 O=gpurun_out/r3prof
 mkdir -p $O
 bash tools/collect_profiles.sh r3 > $O/collect_r3.log 2>&1 || echo "collect r3 failed"

@@ -1,6 +1,6 @@
 set -o pipefail
 export TMPDIR=/tmp
-export KERNEL_FILTER=', 2>(vigo::SolveArgs'
+export KERNEL_FILTER=', false, 2, '
 O=gpurun_out/r3prof
 mkdir -p $O
 bash tools/collect_profiles.sh r3_fast --precision f64_fast > $O/collect_r3_fast.log 2>&1 || echo "collect r3_fast failed"
