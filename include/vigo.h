@@ -209,8 +209,9 @@ int vigo_cost_grad(vigo_handle_t h, int B, int N, const double* ctrl,
  * <= 6e-14 m over 50 iterations).  The deviation is ~12 orders of magnitude inside the 1e-4 parity bar, and exact for
  * a path that is level to the bit (decided once per call, from the control points the call starts with).  What it
  * buys: waves whose trajectories are all level are solved (calls without obstacles, N <= 64) by an instantiation
- * that carries x and y only — two thirds of the L-BFGS history in LDS, of
- * every dot product and of the stencils (-8 % at 1024 x 32, -20 % on batches that fill the chip).  The rule is applied
+ * that carries x and y only — two thirds of the L-BFGS history, of every dot product and of the stencils, and on
+ * batches that fill the chip most of that history in registers, so that a CU holds eight waves instead of four
+ * (-8 % at 1024 x 32, -35 % on such batches).  The rule is applied
  * per trajectory, also where a level trajectory shares a wave with one that is not: results never depend on the
  * batch a trajectory travels in.  The oracle's device-emulation mode applies the same rule; its reference-order mode
  * restates the reference and does not.
