@@ -27,6 +27,13 @@ for case in range(cases):
     n_obs = int(rng.choice([0, 0, 1, 3, 17]))
     P.pred_horizon = float(rng.choice([2.0, 2.0, 0.5, 3.0, 12.0]))   # 11 / 3 / 16 / 61 predicted steps per obstacle
     fast = bool(rng.integers(0, 2))
+    if rng.random() < 0.04:
+        # a batch with more waves than the chip has SIMDs: the register-capped instantiations (two waves per SIMD; the
+        # level kernels with 4 / 5 history pairs in registers)
+        N = int(rng.choice([16, 21, 22, 27, 32, 33, 48, 64]))
+        B = int(rng.integers(2100, 2700)) if N <= 32 else int(rng.integers(1050, 1400))
+        n_obs = int(rng.choice([0, 0, 0, 1]))
+        P.max_iterations = int(rng.choice([5, 18, 30]))
     # level trajectories, trajectories with vertical jitter, or both in one batch (the level rule and its D = 2 kernel);
     # some of the level ones level to the bit, some with a vertical offset of a few ulps (inside / around the 2^-40 band)
     zj = float(rng.choice([0.0, 0.0, 0.03]))
