@@ -51,6 +51,31 @@ int main() {
         vigo_host::parallelFor(out.size(), [&](size_t i) { out[i] = 1; });
         if (std::accumulate(out.begin(), out.end(), 0) != 300) ++bad;
     }
-    std::printf("%s\n", bad.load() ? "FAILED" : "worker pool: 1500 parallelFor calls from 5 caller threads, all sums right; nested and throwing jobs handled");
+    // the companion threads of makePlanBatch: jobs started and awaited in turn from two caller threads, each with its own
+    // companions, the jobs themselves running parallelFor on the companion's own pool; a throwing job ends cleanly
+    {
+        auto user = [&](int seed) {
+            vigo_host::Companion comp[3];
+            for (int rep = 0; rep < 40; ++rep) {
+                std::vector<long> sums(3, 0);
+                for (int k = 0; k < 3; ++k)
+                    comp[k].start([&sums, k, rep, seed]() {
+                        std::vector<int> out(200 + 10 * k, 0);
+                        vigo_host::parallelFor(out.size(), [&](size_t i) { out[i] = (int)i + rep + seed; });
+                        sums[k] = std::accumulate(out.begin(), out.end(), 0L);
+                        if (rep == 7 && k == 1) throw std::runtime_error("job failed");
+                    });
+                for (int k = 0; k < 3; ++k) comp[k].wait();
+                for (int k = 0; k < 3; ++k) {
+                    const long n = 200 + 10 * k;
+                    if (sums[k] != n * (n - 1) / 2 + n * (rep + seed)) ++bad;
+                }
+            }
+        };
+        std::thread other(user, 5);
+        user(9);
+        other.join();
+    }
+    std::printf("%s\n", bad.load() ? "FAILED" : "worker pool: 1500 parallelFor calls from 5 caller threads, all sums right; nested and throwing jobs handled; companion threads: 240 jobs from 2 callers");
     return bad.load() != 0;
 }

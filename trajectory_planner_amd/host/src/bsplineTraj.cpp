@@ -1098,57 +1098,7 @@ bool bsplineTraj::optimizeTrajectory() {
 }
 
 namespace {
-// A second host thread kept by a caller of makePlanBatch for the batches it splits in two (below): it lives as long as
-// the calling thread, so its HIP stream, staging buffers and worker pool (all thread_local) are created once.
-class Companion {
-public:
-    Companion() : th_([this]() { this->loop(); }) {}
-    ~Companion() {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        th_.join();
-    }
-    void start(std::function<void()> job) {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            job_ = std::move(job);
-            busy_ = true;
-        }
-        cv_.notify_all();
-    }
-    void wait() {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [this]() { return !busy_; });
-    }
-
-private:
-    void loop() {
-        for (;;) {
-            std::function<void()> job;
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [this]() { return stop_ || (busy_ && job_); });
-                if (stop_) return;
-                job = std::move(job_);
-                job_ = nullptr;
-            }
-            try { job(); } catch (...) { }      // (makePlanBatch reports failure through its result vector)
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                busy_ = false;
-            }
-            cv_.notify_all();
-        }
-    }
-    std::mutex m_;
-    std::condition_variable cv_;
-    std::function<void()> job_;
-    bool busy_ = false, stop_ = false;
-    std::thread th_;
-};
+using vigo_host::Companion;
 std::atomic<size_t> g_pipelineThreshold{2048};
 thread_local bool t_insidePipeline = false;
 }  // namespace
