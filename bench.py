@@ -366,6 +366,22 @@ def main():
         dt = (time.perf_counter() - t1) / k2
         extra["other_mode"] = {"arithmetic": other, "value": B / dt, "unit": "trajectories/s", "ms_per_step": dt * 1e3}
         v.set_precision({"f32": PREC_F32, "f64": PREC_F64, "f64_fast": 2}[args.precision])
+        # (b2) the level rule switched off (vigo_params_t.strict_z = 1): the general kernel alone, the reference's arithmetic on
+        #      the z axis too — what a batch of trajectories with vertical structure costs, and what this batch cost before round 3
+        P.strict_z = 1
+        v.set_params(P)
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / k2
+        extra["level_rule_off"] = {"value": B / dt, "unit": "trajectories/s", "ms_per_step": dt * 1e3,
+                                   "note": "strict_z = 1: every trajectory through the general (x, y, z) kernel; never `value`"}
+        P.strict_z = 0
+        v.set_params(P)
         # (c) fixed work: g_epsilon = 0 switches the convergence exit off, every trajectory runs all iterations
         #     (SURVEY.md §8(d) asks for both; `value` above is the reference-faithful g_epsilon = 0.01)
         geps = float(P.g_epsilon)

@@ -101,7 +101,8 @@ typedef struct vigo_params_s {
     int32_t max_iterations;      /* BT.cpp:698 (200); 0 (= unbounded in lbfgs.hpp) is refused */
     int32_t max_linesearch;      /* LB:948 (40)      */
     int32_t past;                /* LB:945 (0); only 0 is supported */
-    int32_t reserved_;
+    int32_t strict_z;            /* 1: do NOT apply the level rule (below, at vigo_optimize): the reference's arithmetic on the z
+                                    axis whatever the input.  Default 0.  (Was a reserved field: same layout.) */
     double g_epsilon;            /* BT.cpp:699 (0.01) */
     double delta;                /* LB:946 */
     double min_step;             /* LB:949 */
@@ -214,7 +215,7 @@ int vigo_cost_grad(vigo_handle_t h, int B, int N, const double* ctrl,
  * (-8 % at 1024 x 32, -35 % on such batches).  The rule is applied
  * per trajectory, also where a level trajectory shares a wave with one that is not: results never depend on the
  * batch a trajectory travels in.  The oracle's device-emulation mode applies the same rule; its reference-order mode
- * restates the reference and does not.
+ * restates the reference and does not.  vigo_params_t.strict_z = 1 switches the rule off for a handle.
  */
 int vigo_optimize(vigo_handle_t h, int B, int N, double* ctrl,
                   const int32_t* guide_off, const double* guide_pv, const uint8_t* guide_unk,

@@ -230,7 +230,7 @@ static double distance_term(const vigo_params_t* P, int N, const double* c, cons
  * evaluations; -1 = decide from the points given (the standalone cost / gradient) */
 static int g_level_pinned = -1;
 static int traj_level(const vigo_params_t* P, int N, const double* c) {
-    if (!g_emu_group || P->plan_in_z) return 0;
+    if (!g_emu_group || P->plan_in_z || P->strict_z) return 0;
     if (g_level_pinned >= 0) return g_level_pinned;
     double mn = INFINITY, mx = -INFINITY;
     for (int i = 0; i < N; ++i) { mn = fmin(mn, c[3 * i + 2]); mx = fmax(mx, c[3 * i + 2]); }

@@ -464,6 +464,38 @@ def test_level_rule_on_mixed_batches(vigo_handle, small_world, N, B, n_obs, prec
     assert (rel <= TOL).all() and zdev < 1e-12
 
 
+
+@pytest.mark.parametrize("N,B", [(32, 200), (64, 60)])
+def test_strict_z_switches_the_level_rule_off(vigo_handle, small_world, N, B):
+    """vigo_params_t.strict_z = 1: no level rule — the reference's arithmetic on the z axis whatever the input (the general
+    kernel alone, as before round 3).  Bit-identical to the emulation oracle under the same switch; the z of a trajectory
+    that is level only to rounding now drifts by that rounding noise, exactly as in the reference-order oracle's run."""
+    v = vigo_handle
+    P = default_params()
+    P.max_iterations = 50
+    P.strict_z = 1
+    v.set_params(P)
+    b = synth.make_bspline_batch(small_world, B, N, 990 + N, start_range=3.0)
+    r, d = solve_both(v, P, b)
+    cost, grad, terms = v.cost_grad(**d)
+    with emulation(N):
+        e = ol.optimize_batch(P, b)
+        ce, ge, te = ol.cost_grad_batch(P, b)
+    g = {k: getattr(r, k).cpu().numpy() for k in ("ctrl", "x", "status", "fx", "iters", "evals")}
+    assert np.array_equal(cost.cpu().numpy(), ce) and np.array_equal(grad.cpu().numpy(), ge)
+    for k in ("status", "iters", "evals", "x", "ctrl", "fx"):
+        assert np.array_equal(g[k], e[k]), f"{k} differs from the emulation-mode oracle"
+    drift = np.abs(g["ctrl"][:, 3:-3, 2] - b.ctrl[:, 3:-3, 2]).max(1)
+    assert (drift > 0).mean() > 0.5 and drift.max() < 1e-11          # z moves, by rounding noise
+    P.strict_z = 0
+    v.set_params(P)
+    r2, _ = solve_both(v, P, b)
+    assert np.array_equal(r2.ctrl.cpu().numpy()[:, :, 2], b.ctrl[:, :, 2])     # the rule back on: z untouched
+    rel = rel_err_per_traj(r2.ctrl.cpu().numpy(), g["ctrl"])
+    print(f"\n[strict_z N={N}] z drift without the rule: max {drift.max():.2e}; with vs without the rule: max rel. difference of control points {rel.max():.2e}")
+    assert rel.max() < 1e-6
+
+
 def test_parameter_variations_stay_bit_exact(vigo_handle, small_world):
     """Paths of the kernel the default batch does not reach: more obstacles than the LDS cache holds (20 > 16:
     the rest is read from HBM/L2), three or more guide pairs on a control point (beyond the two kept in

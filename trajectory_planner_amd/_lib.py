@@ -32,7 +32,7 @@ class VigoParams(C.Structure):
         ("max_iterations", C.c_int32),
         ("max_linesearch", C.c_int32),
         ("past", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("strict_z", C.c_int32),
         ("g_epsilon", C.c_double),
         ("delta", C.c_double),
         ("min_step", C.c_double),

@@ -24,6 +24,7 @@ struct DevConst {
     double ts, thr_dyn, oa, ob, oc;
     int pred_num;
     int plan_in_z;
+    int strict_z;      // 1: no level rule
     // default weights
     double w[4];
     // L-BFGS (LB:87-191)

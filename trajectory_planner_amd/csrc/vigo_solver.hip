@@ -709,7 +709,7 @@ __device__ __forceinline__ void set_level(const DevConst& K, LaneProblem<T, PPL>
         if (Q.has_pt[q]) { mn = fmin(mn, (double)x[q][2]); mx = fmax(mx, (double)x[q][2]); }
     }
     group_minmax<GROUP>(mn, mx);
-    Q.level = !K.plan_in_z && (mx - mn) <= 0x1p-40 * fmax(1.0, fmax(fabs(mn), fabs(mx)));
+    Q.level = !K.plan_in_z && !K.strict_z && (mx - mn) <= 0x1p-40 * fmax(1.0, fmax(fabs(mn), fabs(mx)));
 }
 
 template <typename T, int PPL>
@@ -1521,6 +1521,7 @@ DevConst make_dev_const(const vigo_params_t& P) {
     K.oc = pow(P.dist_thresh_dynamic, 3);
     K.pred_num = (int)(P.pred_horizon / P.ts);
     K.plan_in_z = P.plan_in_z;
+    K.strict_z = P.strict_z != 0;
     K.w[0] = P.w_distance; K.w[1] = P.w_smoothness; K.w[2] = P.w_feasibility; K.w[3] = P.w_dynamic;
     K.mem_size = P.mem_size;
     K.max_iterations = P.max_iterations;
@@ -1615,7 +1616,7 @@ static int launch_optimize_t(hipStream_t s, const SolveArgs& a_in, const DevCons
     // trajectory's z is untouched by the first launch, so the second still sees it level and skips it — the other way
     // round, a trajectory just outside the band that the general solve smooths into it would be solved a second time.
     constexpr bool kHasLevel = VIGO_LEVEL_KERNEL && PPL == 1 && !OBS;
-    const bool two = kHasLevel && !k.plan_in_z;
+    const bool two = kHasLevel && !k.plan_in_z && !k.strict_z;
     a.level_waves_elsewhere = two ? 1 : 0;
     const size_t lds = optimize_lds_bytes<T, GROUP, FAST, 3>(a.N, k.mem_size, PPL, a.obs != nullptr);
     if (lds > kLdsPerWorkgroup) return (int)hipErrorInvalidValue;  // refused earlier by vigo_optimize
@@ -1691,7 +1692,7 @@ int launch_optimize(hipStream_t s, const SolveArgs& a, const DevConst& k, const 
     // than SIMDs (8 % slower there): those keep the general kernel, which treats a missing list as no obstacles.
     // (Only where the level instantiation cannot apply — z planning on: with it, level waves go to the D = 2 kernel, 20 %
     // faster than either, and the corner is not worth keeping them from it.)
-    if (precision == VIGO_PREC_F64_FAST && a.N > 32 && a.N <= 64 && L.simd_count > 0 && a.B > L.simd_count && (k.plan_in_z || !VIGO_LEVEL_KERNEL))
+    if (precision == VIGO_PREC_F64_FAST && a.N > 32 && a.N <= 64 && L.simd_count > 0 && a.B > L.simd_count && (k.plan_in_z || k.strict_z || !VIGO_LEVEL_KERNEL))
         return launch_optimize_with_obstacles(s, a, k, kd, precision, L);
     return launch_optimize_o<false>(s, a, k, kd, precision, L);
 }
