@@ -341,7 +341,7 @@ def test_fast_mode_matches_its_emulation_and_the_reference_gate(vigo_handle, sma
     v.set_precision(PREC_F64)
 
 
-@pytest.mark.parametrize("mode", ["f64", "f64_fast"])
+@pytest.mark.parametrize("mode", ["f64", "f64_fast", "f64_strict_z"])
 @pytest.mark.parametrize("name,n,n_boxes,centre,B,N,start", [("configs[1]", 256, 200, 12.0, 1024, 32, 8.0),
                                                             ("configs[3] shard", 512, 800, 24.0, 8192, 64, 16.0)])
 def test_baseline_sizes_in_full(vigo_handle, name, n, n_boxes, centre, B, N, start, mode):
@@ -349,7 +349,9 @@ def test_baseline_sizes_in_full(vigo_handle, name, n, n_boxes, centre, B, N, sta
     size, the bench.py workloads themselves: every trajectory bit-exact vs the emulation-mode oracle and
     within 1e-4 of the reference-order oracle (the oracle needs ~0.1 s / ~5 s for them) — in the reference-order
     arithmetic (`value` of bench.py) AND in the f64_fast mode bench.py quotes as `other_mode` (explicit fma, one
-    reciprocal per history pair): bit-exact against its own emulation, the same 1e-4 bar on every trajectory."""
+    reciprocal per history pair): bit-exact against its own emulation, the same 1e-4 bar on every trajectory.
+    These batches are level (paths at z = 1.0), so they run the level instantiations; `f64_strict_z`
+    (vigo_params_t.strict_z = 1: no level rule) sends the same batches through the GENERAL kernel, as round 2 did."""
     from trajectory_planner_amd.vigo import PREC_F64, PREC_F64_FAST
     v = vigo_handle
     cfg = 2 if N == 32 else 4
@@ -357,6 +359,7 @@ def test_baseline_sizes_in_full(vigo_handle, name, n, n_boxes, centre, B, N, sta
     b = synth.make_bspline_batch(world, B, N, synth.SEED_BASE + cfg + 1000, start_range=start)
     P = default_params()
     P.max_iterations = 50
+    P.strict_z = 1 if mode == "f64_strict_z" else 0
     v.set_params(P)
     v.set_grid(to_dev(world.voxels, v.device), world.origin, world.res)
     d = batch_to_dev(b, v.device)
