@@ -66,14 +66,18 @@ def oracle_rounds(P, world, b, weights, state, gate_dt, max_rounds, ncr=0.0):
 
 # (ncr = notCheckRatio_, BT.h:58 — 0.0 in the reference; a non-zero value shortens the static gate, BT.h:313, and the
 # range findCollisionSeg walks, BT.cpp:406, but not the dynamic gate, BT.h:345)
-@pytest.mark.parametrize("N,B,n_obs,fail0,rounds,ncr", [(32, 96, 0, 0, 1, 0.0), (32, 200, 2, 0, 4, 0.0), (20, 64, 1, 3, 3, 0.0), (64, 40, 0, 2, 2, 0.0),
-                                                         (100, 12, 1, 0, 2, 0.0), (32, 160, 1, 1, 3, 1.0 / 3.0), (48, 64, 0, 0, 2, 0.6)])
-def test_rebound_rounds_match_the_oracle(small_world, N, B, n_obs, fail0, rounds, ncr):
+# (zj > 0: 40 % of the trajectories get vertical jitter, so the compacted active set of every round pairs level with
+# non-level trajectories in new ways — the level rule is per trajectory, whichever kernel and wave carries it)
+@pytest.mark.parametrize("N,B,n_obs,fail0,rounds,ncr,zj", [(32, 96, 0, 0, 1, 0.0, 0.0), (32, 200, 2, 0, 4, 0.0, 0.0), (20, 64, 1, 3, 3, 0.0, 0.0),
+                                                            (64, 40, 0, 2, 2, 0.0, 0.0), (100, 12, 1, 0, 2, 0.0, 0.0), (32, 160, 1, 1, 3, 1.0 / 3.0, 0.0),
+                                                            (48, 64, 0, 0, 2, 0.6, 0.0), (32, 180, 0, 1, 4, 0.0, 0.03), (64, 50, 0, 0, 3, 0.0, 0.03),
+                                                            (24, 90, 1, 0, 3, 0.0, 0.03)])
+def test_rebound_rounds_match_the_oracle(small_world, N, B, n_obs, fail0, rounds, ncr, zj):
     P = default_params()
     P.max_iterations = 40
     v = Vigo(0, P)
     v.set_grid(to_dev(small_world.voxels, v.device), small_world.origin, small_world.res)
-    b = synth.make_bspline_batch(small_world, B, N, 700 + N + B, start_range=3.5, n_obs=n_obs)
+    b = synth.make_bspline_batch(small_world, B, N, 700 + N + B, start_range=3.5, n_obs=n_obs, z_jitter=zj, z_share=0.4)
     rng = np.random.default_rng(N + B)
     weights = np.tile(np.array([P.w_distance, P.w_smoothness, P.w_feasibility, P.w_dynamic]), (B, 1))
     weights[:, 0] *= rng.choice([1.0, 2.0, 4.0], size=B)
