@@ -295,14 +295,19 @@ def host_guides(world: World, N: int, paths: Optional[np.ndarray] = None, ctrl: 
     ctrl_out = np.zeros((n, N, 3))
     status, n_seg = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
     goff = np.zeros(n * N + 1, dtype=np.int32)
-    cap = 64 * n * 4 + 1024
-    gpv = np.zeros((cap, 6))
     null = C.cast(None, dp)
-    rc = lib.vigo_host_bspline_guides_batch(vox.ctypes.data_as(C.c_void_p), dims, origin.ctypes.data_as(dp), float(world.res), n,
-                                            src.shape[1] if ctrl is None else 0, src.ctypes.data_as(dp) if ctrl is None else null,
-                                            src.ctypes.data_as(dp) if ctrl is not None else null, N, cfg.ctypes.data_as(dp),
-                                            ctrl_out.ctypes.data_as(dp), status.ctypes.data_as(ip), n_seg.ctypes.data_as(ip),
-                                            goff.ctypes.data_as(ip), gpv.ctypes.data_as(dp), cap)
+    cap = 16 * n + 1024            # guide pairs the output can take; grown when the library says it does not fit (-2)
+    while True:
+        gpv = np.zeros((cap, 6))
+        rc = lib.vigo_host_bspline_guides_batch(vox.ctypes.data_as(C.c_void_p), dims, origin.ctypes.data_as(dp), float(world.res), n,
+                                                src.shape[1] if ctrl is None else 0, src.ctypes.data_as(dp) if ctrl is None else null,
+                                                src.ctypes.data_as(dp) if ctrl is not None else null, N, cfg.ctypes.data_as(dp),
+                                                ctrl_out.ctypes.data_as(dp), status.ctypes.data_as(ip), n_seg.ctypes.data_as(ip),
+                                                goff.ctypes.data_as(ip), gpv.ctypes.data_as(dp), cap)
+        if rc == -2 and cap < 64 * n * N:
+            cap *= 4
+            continue
+        break
     if rc != 0:
         raise RuntimeError(f"vigo_host_bspline_guides_batch failed ({rc})")
     return ctrl_out, status, n_seg, goff, np.ascontiguousarray(gpv[:goff[-1]])
