@@ -14,6 +14,7 @@ CASES = ((1024, 32, 0), (1024, 32, 2), (16384, 32, 0), (8192, 64, 0)) if not os.
 for (B, N, prec) in CASES:
     b = synth.make_bspline_batch(w256, B, N, 4242 + N + B, start_range=8.0)
     P = default_params(); P.max_iterations = 50
+    P.strict_z = 1 if os.environ.get('VIGO_EXP_STRICT') else 0   # 1: the general kernel (no level rule)
     v = Vigo(0, P, prec)
     v.set_grid(T(w256.voxels), w256.origin, w256.res)
     ctrl, goff, gpv = T(b.ctrl), T(b.guide_off), T(b.guide_pv)
