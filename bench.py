@@ -528,9 +528,9 @@ def main():
         pv = pmc_view(args.precision, args.workload, kern_ms, waves, simds, build_id) if not args.batch else {"pmc_source": None}
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pv.get("traffic"),
-                "kernel": "vigo::k_optimize (two launches per solve since round 3: the general instantiation, whose waves of level "
-                          "trajectories exit at once, then the level instantiation <..., D = 2>, which does the work on this batch; "
-                          "kernel_ms = HIP events around both)",
+                "kernel": "vigo::k_optimize (two launches per solve since round 3: first the level instantiation <..., D = 2>, "
+                          "which does the work on this batch, then the general instantiation, whose waves of level trajectories "
+                          "exit at once; kernel_ms = HIP events around both)",
                 "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
                 "byte_model": "SURVEY.md §8(d) streaming model x fp64 (state streamed per BLAS-1 pass, as the CPU "
                               "reference does); the kernel keeps that state in LDS/VGPRs, so HBM sees only the "
