@@ -396,6 +396,12 @@ int vigo_poly_sample(vigo_handle_t h, int S, int deg, const double* coeffs, cons
  * k-fold floating-point accumulation, evaluated in closed form (host utility, no GPU). */
 double vigo_accumulated_time(double delT, int64_t k);
 
+/* The same clock through the table vigo_corridor_check builds once per segment (csrc/vigo_exact_time.hpp: one piece
+ * per run of equal increments, a binary search per lookup): t_k for 0 <= k <= k_last from the table made for k_last,
+ * or NaN when the kernel would build none (delT outside [2^-1000, 1e300), more than 128 pieces) and fall back to
+ * vigo_accumulated_time.  Host utility for the tests (no GPU): must equal vigo_accumulated_time(delT, k) bit for bit. */
+double vigo_clock_table_time(double delT, int64_t k_last, int64_t k);
+
 /* pow(t, d) of polyTrajSolver::getPose (PS.cpp:1035-1039) for an integer 0 <= d <= 15 as the sampler kernels
  * evaluate it: the CORRECTLY ROUNDED power (libm's pow returns it or its neighbour, depending on the libm
  * build).  Host utilities, no GPU:

@@ -79,6 +79,30 @@ def test_accumulated_time_equals_the_reference_loop():
     assert lib.vigo_accumulated_time(0.0, 5) == 0.0
 
 
+def test_clock_table_equals_the_reference_loop():
+    """The per-segment clock table of the corridor checker (csrc/vigo_exact_time.hpp: build_clock_table / clock_at) gives
+    the k-fold `t += d` of polyTrajSolver.cpp:1129 bit for bit at EVERY k, for clocks of config-3 size, powers of two
+    (every step exact), ties (d = 1 + ulp scaled), long runs, and says "no table" where the kernel falls back."""
+    lib = _lib.load()
+    rng = np.random.default_rng(8)
+    cases = [(float(d), 10000) for d in rng.uniform(1e-4, 5e-4, 6)]
+    cases += [(float(np.ldexp(rng.uniform(0.5, 1.0), int(e))), int(rng.integers(1, 40000))) for e in rng.integers(-40, 12, 24)]
+    cases += [(2.0 ** -10, 5000), (3 * 2.0 ** -20, 70000), (float(np.ldexp(1.0 + 2.0 ** -52, -10)), 30000), (0.1, 1), (0.1, 2), (1e-3, 400000)]
+    for d, n in cases:
+        t = 0.0
+        stride = 1 if n <= 40000 else 7
+        for k in range(n):
+            if k % stride == 0 or k == n - 1:
+                assert lib.vigo_clock_table_time(d, n - 1, k) == t, (d, n, k)
+            t = t + d
+    # piece boundaries of a long run, against the closed form the table must agree with
+    d, n = 4.56e-4, 3_000_000
+    for k in [0, 1, 2, 3, 4, 7, 8, 9, 1023, 1024, 4095, 4096, 4097, 2_999_999] + [int(x) for x in rng.integers(0, n, 300)]:
+        assert lib.vigo_clock_table_time(d, n - 1, k) == lib.vigo_accumulated_time(d, k), k
+    for d in (0.0, -0.1, float("nan"), float("inf"), 1e-310, 2e300):
+        assert np.isnan(lib.vigo_clock_table_time(d, 100, 5))
+
+
 def test_exact_pow_is_the_correctly_rounded_power(olib):
     """vigo_exact_pow (the sampler kernels' pow(t, d), polyTrajSolver.cpp:1035-1039) and the oracle's independent
     vgo_pow_exact both equal the exactly rounded rational power; the double-double tier alone is right whenever it

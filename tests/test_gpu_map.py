@@ -143,6 +143,43 @@ def test_corridor_checker_matches_oracle(vigo_handle):
         assert f == flag2.cpu().numpy()[s]
 
 
+@pytest.mark.parametrize("box,map_res", [((0.4, 0.4, 0.2), 0.2), ((0.6, 0.3, 0.2), 0.1), ((0.55, 0.47, 0.23), 0.2), ((1.0, 0.9, 0.3), 0.2)])
+def test_corridor_span_certificates_and_what_they_refuse(vigo_handle, box, map_res):
+    """The checker decides spans of 32 / 16 samples at once where it can prove every sample's verdict (vigo_corridor.hip,
+    SpanConst) and hands the rest to the per-sample walk: flags, first indices and counts must be the reference walk's
+    (PO.cpp:547-589, :634-656) whatever route a segment takes — long slow segments (certificates), a box that is an
+    exact multiple of map_resolution (the lattice count then changes from pose to pose with the rounding of
+    fx +- box / 2: the verdict per choice of counts), sample counts either side of the one-sample-per-lane limit, fast
+    segments, segments that leave the map or start outside it, non-finite coefficients (a pose at infinity does NOT
+    collide: x86's conversion of the NaN count), clocks that stand still, run backwards or barely move, a box of more
+    than three cells per axis (the last parameter set)."""
+    v = vigo_handle
+    w = maze_like_world()
+    set_world(v, w)
+    g, keep = ol.make_grid(w)
+    O = ol.oracle()
+    box = np.array(box)
+    coeffs, n_samp, delT, dur = synth.make_corridor_segments(51, 40, extent_lo=(-4, -4, 0.6), extent_hi=(4, 4, 1.6), n_samples=9000)
+    n_samp[:8] = [511, 512, 513, 1023, 1025, 4096, 8191, 33]
+    coeffs[8, :, 1:] *= 40.0                               # samples further apart than a voxel
+    coeffs[9, :, 1] *= 6.0
+    coeffs[10, 0, 0] += 9.0                                # outside the map for good
+    coeffs[11, 1, 0], coeffs[11, 1, 1] = -4.7, -0.4        # walks out of it
+    coeffs[12, 0, 3] = np.inf
+    coeffs[13, 2, 0] = np.nan
+    coeffs[14, 1, 5] = 1e300
+    delT[15], delT[16], delT[17] = 0.0, -delT[16], delT[17] * 1e-9
+    n_samp[15:17] = 2500
+    coeffs[18, :, 1:] = 0.0                                # a segment that does not move
+    flag, first, count = (x.cpu().numpy() for x in v.corridor_check(to_dev(coeffs, v.device), to_dev(n_samp, v.device), to_dev(delT, v.device), box, map_res))
+    for s in range(len(coeffs)):
+        fi, cn = C.c_int(), C.c_int()
+        c = np.ascontiguousarray(coeffs[s])
+        f = O.vgo_corridor_check_segment(C.byref(g), 7, ol._d(c), int(n_samp[s]), float(delT[s]), ol._d(box), map_res, C.byref(fi), C.byref(cn))
+        assert (f, fi.value, cn.value) == (flag[s], first[s], count[s]), (s, f, fi.value, cn.value, flag[s], first[s], count[s])
+    assert 0 < flag.mean() < 1
+
+
 def test_inflate_grid_matches_numpy_dilation(vigo_handle):
     """vigo_inflate_grid: bit0 = box dilation of bit2 (integer/byte work: bit-exact), other bits kept, in place"""
     v = vigo_handle

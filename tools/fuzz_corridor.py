@@ -35,19 +35,42 @@ for case in range(cases):
         v.set_metric_bounds(bmin, bmax); g.bmin[:] = list(bmin); g.bmax[:] = list(bmax)
     box = rng.uniform(0.1, 1.3, size=3) * [1, 1, 0.5]
     map_res = float(rng.choice([0.05, 0.1, 0.2, 0.25, 0.45]))
-    deg = int(rng.integers(3, 10))
+    if rng.random() < 0.4:
+        # box an exact multiple of map_resolution: the lattice count (int)((xmax - xmin) / map_res) then wobbles between
+        # two values with the rounding of fx +- box / 2 (the span certificates' nlo != nhi case)
+        map_res = float(rng.choice([0.1, 0.2]))
+        box = map_res * rng.integers(1, 4, size=3).astype(np.float64)
+    deg = int(rng.integers(3, 10)) if rng.random() < 0.6 else 7
     half = n * res / 2
     S = 24
+    # sample counts: one sample per lane (<= 512), certified spans of 16 / 64 samples above that
+    n_samples = int(rng.choice([int(rng.integers(50, 1500)), int(rng.integers(1500, 6000)), int(rng.integers(6000, 20000))]))
     coeffs, n_samp, delT, dur = synth.make_corridor_segments(int(rng.integers(1 << 30)), S, deg=deg, extent_lo=(-half * 0.9, -half * 0.9, 0.0),
-                                                             extent_hi=(half * 0.9, half * 0.9, 1.6), n_samples=int(rng.integers(50, 1500)))
+                                                             extent_hi=(half * 0.9, half * 0.9, 1.6), n_samples=n_samples)
     n_samp[:4] = [0, 1, 17, 33]
+    n_samp[4:8] = [511, 512, 513, 1025]
+    # segments the certificates must refuse or decide as a whole: fast ones (samples further apart than a voxel), one that
+    # leaves the map, one that starts far outside, non-finite coefficients, clocks that do not advance or run backwards
+    coeffs[8, :, 1:] *= 40.0
+    coeffs[9, :, 1] *= 6.0
+    coeffs[10, 0, 0] += 3.0 * half
+    coeffs[11, 1, 0] = -half + 0.05
+    coeffs[11, 1, 1] = -abs(coeffs[11, 1, 1])
+    if rng.random() < 0.5:
+        coeffs[12, int(rng.integers(0, 3)), int(rng.integers(0, deg + 1))] = float(rng.choice([np.nan, np.inf, -np.inf, 1e300]))
+    delT[13] = 0.0
+    delT[14] = -delT[14]
+    delT[15] = delT[15] * 1e-9
+    n_samp[13:15] = np.minimum(n_samp[13:15], 3000)         # (the oracle and the device walk these clocks step by step)
     flag, first, count = (x.cpu().numpy() for x in v.corridor_check(to_dev(coeffs, v.device), to_dev(n_samp, v.device), to_dev(delT, v.device), box, map_res))
     ok = True
     for s in range(S):
         fi, cn = C.c_int(), C.c_int()
         c = np.ascontiguousarray(coeffs[s])
         f = O.vgo_corridor_check_segment(C.byref(g), deg, ol._d(c), int(n_samp[s]), float(delT[s]), ol._d(box), map_res, C.byref(fi), C.byref(cn))
-        ok = ok and (f, fi.value, cn.value) == (flag[s], first[s], count[s])
+        if (f, fi.value, cn.value) != (flag[s], first[s], count[s]):
+            ok = False
+            print(json.dumps({"segment": s, "n": int(n_samp[s]), "oracle": [int(f), fi.value, cn.value], "device": [int(flag[s]), int(first[s]), int(count[s])]}), flush=True)
     # the per-pose sweep on random poses
     pts = rng.uniform(-half * 1.1, half * 1.1, size=(400, 3)) * [1, 1, 0.2] + [0, 0, 0.8]
     got = v.box_collision_points(to_dev(pts, v.device), box, map_res).cpu().numpy()

@@ -2,6 +2,9 @@
 256 x 256 x 64 world of tools/measure_configs.py; prints one JSON line.  Run on the GPU box."""
 import json, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import trajectory_planner_amd._lib as L
+if os.environ.get("VIGO_EXP_LIB"):                      # dev: an alternative build of the library
+    L.LIB_PATH = os.path.join(R, os.environ["VIGO_EXP_LIB"])
 import numpy as np, torch
 from trajectory_planner_amd import synth
 from trajectory_planner_amd.vigo import Vigo
@@ -23,4 +26,4 @@ for _ in range(3): v.corridor_check(c, ns, dl, box, 0.2)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): flag, first, count = v.corridor_check(c, ns, dl, box, 0.2)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
-print(json.dumps({"config": "3: 4096 segments x 10k samples", "ms": dt * 1e3, "samples_per_s": 4096e4 / dt, "colliding_segments": int(flag.sum())}))
+print(json.dumps({"lib": os.environ.get("VIGO_EXP_LIB", "default"), "config": "3: 4096 segments x 10k samples", "ms": dt * 1e3, "samples_per_s": 4096e4 / dt, "colliding_segments": int(flag.sum())}))

@@ -85,6 +85,7 @@ PROTOTYPES = {
     "vigo_box_collision_points": (_i, [_vp, _i64, _vp, _d3, _d, _vp]),
     "vigo_poly_sample": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "vigo_accumulated_time": (_d, [_d, _i64]),
+    "vigo_clock_table_time": (_d, [_d, _i64, _i64]),
     "vigo_exact_pow": (_d, [_d, _i]),
     "vigo_exact_pow_dd": (_d, [_d, _i, C.POINTER(_i)]),
     "vigo_exact_pow_integer": (_d, [_d, _i]),

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "vigo_exact_pow.hpp"
+#include "vigo_corridor.hpp"
 #include "vigo_exact_time.hpp"
 #include "build/vigo_build_id.h"
 #include "vigo_internal.hpp"
@@ -174,6 +175,14 @@ extern "C" {
 
 int vigo_abi_version(void) { return 1; }
 double vigo_accumulated_time(double delT, int64_t k) { return vigo::accumulated_time(delT, k); }
+double vigo_clock_table_time(double delT, int64_t k_last, int64_t k) {
+    if (k_last < 0 || k < 0 || k > k_last || k_last > (int64_t)1 << 30) return NAN;
+    vigo::ClockTable C;
+    const double t_last = vigo::build_clock_table(delT, (int)k_last, C);
+    if (C.n <= 0) return NAN;
+    if (k == k_last && vigo::clock_at(C, (int)k) != t_last) return NAN;     // (the builder's own last value)
+    return vigo::clock_at(C, (int)k);
+}
 double vigo_exact_pow_dd(double t, int d, int* ambiguous) {
     // the first tier as the sampler kernels run it: t^0 = 1, t^1 = t, then the running double-double product
     bool amb = false;
@@ -640,8 +649,11 @@ int vigo_corridor_check(vigo_handle_t h, int S, int deg, const double* coeffs, c
         if (fabs(q - floor(q + 0.5)) > 1e-6)
             return fail(h, VIGO_ERR_UNSUPPORTED, "corridor checker needs a grid origin that is a multiple of res (octomap keys)");
     }
-    VIGO_HIP(h, (hipError_t)vigo::launch_corridor_check(h->stream, h->grid, S, deg, coeffs, n_samp, delT, box, map_res,
-                                                        out_flag, out_first, out_count));
+    if (S == 0) return VIGO_OK;
+    int rc = ensure_scratch(h, (size_t)S * sizeof(int));      // the first pass' work list for the second
+    if (rc != VIGO_OK) return rc;
+    VIGO_HIP(h, (hipError_t)vigo::launch_corridor_check2(h->stream, h->grid, S, deg, coeffs, n_samp, delT, box, map_res,
+                                                         out_flag, out_first, out_count, static_cast<int*>(h->scratch)));
     return VIGO_OK;
 }
 

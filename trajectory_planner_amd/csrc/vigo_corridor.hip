@@ -15,6 +15,7 @@
 // A tile too large for the LDS budget falls back to lookups in the packed planes (L2).
 #include <type_traits>
 
+#include "vigo_corridor.hpp"
 #include "vigo_exact_pow.hpp"
 #include "vigo_exact_time.hpp"
 #include "vigo_grid.hpp"
@@ -25,7 +26,7 @@ namespace {
 constexpr int kChunk = 16;       // consecutive samples per thread visit
 constexpr int kBlock = 256;
 constexpr int kMaxDeg = 15;
-constexpr int kQueueCap = 1024;   // LDS queue of samples for the exact-power pass of k_corridor
+constexpr int kQueueCap = 512;    // LDS queue of samples for the exact-power pass of k_corridor
 
 // collision_box / map_resolution of the sweep and octomap's resolution_factor (1 / tree resolution)
 struct SweepConst {
@@ -41,6 +42,7 @@ struct CorridorArgs {
     int32_t* out_first;
     int32_t* out_count;
     int tile_words_cap;
+    int* todo;           // per segment: 1 = left to the second pass (see k_corridor)
     SweepConst sweep;
 };
 
@@ -137,6 +139,20 @@ __device__ __forceinline__ void poly_fast7(const double (&c7)[3][8], double t, d
     }
     p[0] = x; p[1] = y; p[2] = z;
 }
+// (coefficients from LDS, all lanes one address: the first pass of k_corridor has no registers to hold 24 doubles)
+__device__ __forceinline__ void poly_fast7_lds(const double* cf, double t, double (&p)[3]) {
+    double x = 0, y = 0, z = 0, pw = 1.0;
+    int off = 0;
+    asm volatile("" : "+v"(off));       // (an offset the compiler cannot see through: the loads stay here, not in registers above the loop)
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        x += cf[off + d] * pw;
+        y += cf[off + (kMaxDeg + 1) + d] * pw;
+        z += cf[off + 2 * (kMaxDeg + 1) + d] * pw;
+        pw *= t;
+    }
+    p[0] = x; p[1] = y; p[2] = z;
+}
 __device__ __forceinline__ void poly_fast(const double* cf, int deg, double t, double (&p)[3]) {
     double x = 0, y = 0, z = 0, pw = 1.0;
     for (int d = 0; d <= deg; ++d) {
@@ -153,11 +169,12 @@ __device__ __forceinline__ double uniform_f64(double v) {   // a wave-uniform va
 }
 
 // fast form + filter: true when f holds the certified floats of the exact chain
-template <bool DEG7>
+template <bool DEG7, bool REG = true>
 __device__ __forceinline__ bool sample_f32_fast(const double (&c7)[3][8], const double* cf, int deg, double t,
                                                 const double (&E)[3], float (&f)[3]) {
     double p[3];
-    if (DEG7) poly_fast7(c7, t, p);
+    if (DEG7 && REG) poly_fast7(c7, t, p);
+    else if (DEG7) poly_fast7_lds(cf, t, p);
     else poly_fast(cf, deg, t, p);
     bool ok = true;
 #pragma unroll
@@ -221,10 +238,48 @@ struct SweepMemo {
     bool verdict;
 };
 
+// Range of the lattice counts of a segment's poses and the dividing line between them (k_corridor, see SpanConst):
+// xNum = (int)(((fx + h) - (fx - h)) / map_res) is nlo or nhi = nlo + 1 for every pose of the segment, and it is nhi
+// exactly when the computed difference reaches thr (the smallest double whose quotient truncates to nhi, found per
+// segment by stepping ulps around nhi * map_res) — the same integers as the division, for a compare.
+struct CountConst {
+    int nlo[3], nhi[3];
+    double thr[3];
+};
+
+// OR over the box lattice given per-axis keys (all inside the grid): LDS tile when it holds them, packed planes otherwise
+__device__ __forceinline__ bool lattice_any(const GridView& g, const Tile* T, const uint32_t* tile_words, const int (&kx)[kAxisMax],
+                                            const int (&ky)[kAxisMax], const int (&kz)[kAxisMax], int xNum, int yNum, int zNum) {
+    // keys grow with the lattice index: the tile holds all of them iff it holds the first and last
+    const bool tiled = T && T->in_lds && kx[0] >= T->x0 && kx[xNum] < T->x0 + T->tx && ky[0] >= T->y0 &&
+                       ky[yNum] < T->y0 + T->ty && (kz[0] >> 5) >= T->w0 && (kz[zNum] >> 5) < T->w0 + T->tw;
+    unsigned any = 0u;
+    if (tiled) {
+#pragma unroll
+        for (int xi = 0; xi < kAxisMax; ++xi) {
+            if (xi > xNum) continue;
+#pragma unroll
+            for (int yi = 0; yi < kAxisMax; ++yi) {
+                if (yi > yNum) continue;
+                const int col = ((kx[xi] - T->x0) * T->ty + (ky[yi] - T->y0)) * T->tw - T->w0;
+#pragma unroll
+                for (int zi = 0; zi < kAxisMax; ++zi)
+                    if (zi <= zNum) any |= tile_words[col + (kz[zi] >> 5)] >> (kz[zi] & 31);
+            }
+        }
+        return (any & 1u) != 0;
+    }
+    for (int xi = 0; xi <= xNum; ++xi)
+        for (int yi = 0; yi <= yNum; ++yi)
+            for (int zi = 0; zi <= zNum; ++zi) any |= grid_bits_at(g, kx[xi], ky[yi], kz[zi]) >> 1;  // unknown | occupied
+    return any != 0;
+}
+
 // polyTrajOctomap::checkCollision(point3d) for one pose.  T != nullptr: look the voxels up in the LDS
 // tile when it holds them (it does by construction of the tile; the test costs six compares per pose).
 __device__ __forceinline__ bool box_sweep(const GridView& g, const SweepConst& C, float fx, float fy, float fz,
-                                          const Tile* T, const uint32_t* tile_words, SweepMemo* memo = nullptr) {
+                                          const Tile* T, const uint32_t* tile_words, SweepMemo* memo = nullptr,
+                                          const CountConst* N = nullptr) {
     const double map_res = C.map_res, rf = C.rf;
     // PO.cpp:548-555
     const double xmin = fx - C.box[0] / 2, xmax = fx + C.box[0] / 2;
@@ -233,9 +288,21 @@ __device__ __forceinline__ bool box_sweep(const GridView& g, const SweepConst& C
     // truncation of a ROUNDED quotient whose dividend wobbles by an ulp of fx around the box size: the
     // count can be one short, per pose (replacing the divisions by compares against host-bisected
     // thresholds gives the same integers but measured 5 % slower)
-    const int xNum = (int)((xmax - xmin) / map_res);
-    const int yNum = (int)((ymax - ymin) / map_res);
-    const int zNum = (int)((zmax - zmin) / map_res);
+    // A pose at infinity or NaN makes the quotient NaN (inf - inf).  The conversion is undefined in C++; the reference as
+    // it runs on x86 — and the oracle on this host — gets cvttsd2si's INT_MIN: no pass of the loops, the pose does NOT
+    // collide.  The device conversion would return 0 (one lattice point, outside the bounds: collides), hence the select.
+    int xNum, yNum, zNum;
+    if (N) {                                                        // (wave-uniform)
+        const double dx = xmax - xmin, dy = ymax - ymin, dz = zmax - zmin;
+        xNum = dx == dx ? (dx >= N->thr[0] ? N->nhi[0] : N->nlo[0]) : (int)0x80000000;
+        yNum = dy == dy ? (dy >= N->thr[1] ? N->nhi[1] : N->nlo[1]) : (int)0x80000000;
+        zNum = dz == dz ? (dz >= N->thr[2] ? N->nhi[2] : N->nlo[2]) : (int)0x80000000;
+    } else {
+        const double qxn = (xmax - xmin) / map_res, qyn = (ymax - ymin) / map_res, qzn = (zmax - zmin) / map_res;
+        xNum = qxn == qxn ? (int)qxn : (int)0x80000000;
+        yNum = qyn == qyn ? (int)qyn : (int)0x80000000;
+        zNum = qzn == qzn ? (int)qzn : (int)0x80000000;
+    }
     bool hit = false;
     if (xNum < kAxisMax && yNum < kAxisMax && zNum < kAxisMax && xNum >= 0 && yNum >= 0 && zNum >= 0) {
         int kx[kAxisMax], ky[kAxisMax], kz[kAxisMax];
@@ -253,31 +320,9 @@ __device__ __forceinline__ bool box_sweep(const GridView& g, const SweepConst& C
 #pragma unroll
             for (int i = 0; i < kAxisMax; ++i) { memo->kx[i] = kx[i]; memo->ky[i] = ky[i]; memo->kz[i] = kz[i]; }
         }
-        // keys grow with the lattice index: the tile holds all of them iff it holds the first and last
-        const bool tiled = T && T->in_lds && kx[0] >= T->x0 && kx[xNum] < T->x0 + T->tx && ky[0] >= T->y0 &&
-                           ky[yNum] < T->y0 + T->ty && (kz[0] >> 5) >= T->w0 && (kz[zNum] >> 5) < T->w0 + T->tw;
-        unsigned any = 0u;
-        if (tiled) {
-#pragma unroll
-            for (int xi = 0; xi < kAxisMax; ++xi) {
-                if (xi > xNum) continue;
-#pragma unroll
-                for (int yi = 0; yi < kAxisMax; ++yi) {
-                    if (yi > yNum) continue;
-                    const int col = ((kx[xi] - T->x0) * T->ty + (ky[yi] - T->y0)) * T->tw - T->w0;
-#pragma unroll
-                    for (int zi = 0; zi < kAxisMax; ++zi)
-                        if (zi <= zNum) any |= tile_words[col + (kz[zi] >> 5)] >> (kz[zi] & 31);
-                }
-            }
-            if (memo) memo->verdict = (any & 1u) != 0;
-            return (any & 1u) != 0;
-        }
-        for (int xi = 0; xi <= xNum; ++xi)
-            for (int yi = 0; yi <= yNum; ++yi)
-                for (int zi = 0; zi <= zNum; ++zi) any |= grid_bits_at(g, kx[xi], ky[yi], kz[zi]) >> 1;  // unknown | occupied
-        if (memo) memo->verdict = any != 0;
-        return any != 0;
+        const bool v = lattice_any(g, T, tile_words, kx, ky, kz, xNum, yNum, zNum);
+        if (memo) memo->verdict = v;
+        return v;
     }
     // a collision box of more than 3 map cells per axis: the reference's walk as written
     for (int xi = 0; xi <= xNum && !hit; ++xi) {
@@ -299,19 +344,167 @@ __device__ __forceinline__ bool box_sweep(const GridView& g, const SweepConst& C
     return hit;
 }
 
-// (four waves per SIMD = at most 128 VGPRs: the filter left the allocation at 129)
-__global__ void __launch_bounds__(kBlock, 4) k_corridor(GridView g, CorridorArgs A) {
+// The box lattice's OR for EVERY choice of lattice counts at once (k_corridor's span certificates): bit b of the result,
+// b = bx | by << 1 | bz << 2, is the OR over the lattice with count nhi on the axes whose bit is set and nlo on the
+// others (nhi - nlo <= 1).  A lattice point beyond nlo on an axis belongs to the choices with that axis' bit set only,
+// so one pass over the nhi lattice serves all eight: each lookup ORs its bit into the choices that contain the point.
+// (An axis whose count cannot vary has nlo == nhi: both values of its bit get the same answer.)
+__device__ __forceinline__ unsigned lattice_any_all(const GridView& g, const Tile* T, const uint32_t* tile_words, const int (&kx)[kAxisMax],
+                                                    const int (&ky)[kAxisMax], const int (&kz)[kAxisMax], const CountConst& N) {
+    const int xNum = N.nhi[0], yNum = N.nhi[1], zNum = N.nhi[2];
+    const bool tiled = T->in_lds && kx[0] >= T->x0 && kx[xNum] < T->x0 + T->tx && ky[0] >= T->y0 &&
+                       ky[yNum] < T->y0 + T->ty && (kz[0] >> 5) >= T->w0 && (kz[zNum] >> 5) < T->w0 + T->tw;
+    unsigned tt = 0u;
+    if (!tiled) {                      // (a tile too large for the LDS: rare, kept small)
+#pragma unroll 1
+        for (int i = 0; i < kAxisMax * kAxisMax * kAxisMax; ++i) {
+            const int xi = i >> 4, yi = (i >> 2) & 3, zi = i & 3;
+            if (xi > xNum || yi > yNum || zi > zNum) continue;
+            const unsigned m = (xi > N.nlo[0] ? 0xaau : 0xffu) & (yi > N.nlo[1] ? 0xccu : 0xffu) & (zi > N.nlo[2] ? 0xf0u : 0xffu);
+            if (grid_bits_at(g, kx[xi], ky[yi], kz[zi]) >> 1) tt |= m;
+        }
+        return tt;
+    }
+#pragma unroll
+    for (int xi = 0; xi < kAxisMax; ++xi) {
+        if (xi > xNum) continue;
+        const unsigned mx = xi > N.nlo[0] ? 0xaau : 0xffu;
+#pragma unroll
+        for (int yi = 0; yi < kAxisMax; ++yi) {
+            if (yi > yNum) continue;
+            const unsigned mxy = mx & (yi > N.nlo[1] ? 0xccu : 0xffu);
+            const int col = ((kx[xi] - T->x0) * T->ty + (ky[yi] - T->y0)) * T->tw - T->w0;
+#pragma unroll
+            for (int zi = 0; zi < kAxisMax; ++zi) {
+                if (zi > zNum) continue;
+                const unsigned m = mxy & (zi > N.nlo[2] ? 0xf0u : 0xffu);
+                const unsigned bit = (tile_words[col + (kz[zi] >> 5)] >> (kz[zi] & 31)) & 1u;
+                tt |= (0u - bit) & m;
+            }
+        }
+    }
+    return tt;
+}
+
+// box_sweep for the first pass of k_corridor: the lattice counts by compare (CountConst: each is nlo or nhi < kAxisMax),
+// no memo, no walk for large boxes.  A NaN count (see box_sweep) on any axis: some loop of the reference makes no pass.
+__device__ __forceinline__ bool box_sweep_fast(const GridView& g, const SweepConst& C, const CountConst& N, float fx, float fy,
+                                               float fz, const Tile* T, const uint32_t* tile_words) {
+    const double map_res = C.map_res, rf = C.rf;
+    const double xmin = fx - C.box[0] / 2, xmax = fx + C.box[0] / 2;
+    const double ymin = fy - C.box[1] / 2, ymax = fy + C.box[1] / 2;
+    const double zmin = fz - C.box[2] / 2, zmax = fz + C.box[2] / 2;
+    const double dx = xmax - xmin, dy = ymax - ymin, dz = zmax - zmin;
+    if (!(dx == dx && dy == dy && dz == dz)) return false;
+    const int xNum = dx >= N.thr[0] ? N.nhi[0] : N.nlo[0];
+    const int yNum = dy >= N.thr[1] ? N.nhi[1] : N.nlo[1];
+    const int zNum = dz >= N.thr[2] ? N.nhi[2] : N.nlo[2];
+    bool hit = false;
+    int kx[kAxisMax], ky[kAxisMax], kz[kAxisMax];
+    axis_keys(xmin, xNum, map_res, rf, g.bmin[0], g.bmax[0], g.key0[0], g.nx, kx, hit);
+    axis_keys(ymin, yNum, map_res, rf, g.bmin[1], g.bmax[1], g.key0[1], g.ny, ky, hit);
+    axis_keys(zmin, zNum, map_res, rf, g.bmin[2], g.bmax[2], g.key0[2], g.nz, kz, hit);
+    if (hit) return true;
+    return lattice_any(g, T, tile_words, kx, ky, kz, xNum, yNum, zNum);
+}
+
+// ---- certified spans (k_corridor) -----------------------------------------------------------------------------
+// Consecutive samples are ~0.1 mm apart against 100 mm voxels: nearly every run of 64 samples sees the same voxels.
+// A span of samples [k0, k0 + len) is decided by ONE evaluation when that can be PROVED to give every sample's verdict:
+//   interval  every sample's exact-chain position lies within R of the fast form at one clock value t* inside the span:
+//             R = 2 E (both evaluations are within E / 2 of the real polynomial, see sampler_error_bound) + L * dt, L >= sup |p'|
+//             over the sampled interval (Bernstein coefficients of p' — convex hull — plus 2^-40 sum d |c_d| T^(d-1) for
+//             their own rounding), dt >= |t_k - t*| = (half the span) * |delT| + the drift of the accumulated clock from
+//             k * delT (<= n u T: one rounding of at most u T per step);
+//   floats    conversion to float is monotone: every sample's float lies in [flo, fhi] = [(float)(p - R), (float)(p + R)];
+//   keys      every expression of axis_keys() is a monotone function of the pose's float (a sum with a constant, a
+//             product by a positive constant, conversions and floor all round monotonically), so a lattice point whose
+//             bounds test passes and whose key agrees AT BOTH ENDS has that key for every sample of the span; one that
+//             lies beyond the same bound at both ends is outside for every sample;
+//   count     the lattice count (int)((xmax - xmin) / map_res) wobbles with the rounding of fx +- box / 2: it lies in
+//             [nlo, nhi] computed per segment from |d - box| <= 2^-50 (max |x| + box); the verdict is an OR over the
+//             lattice, monotone in the counts, so equal verdicts for (nlo..) and (nhi..) pin it for anything between.
+// A span that cannot be certified is cut in four and tried again; the last few samples go through the per-sample path.
+// Results are those of the per-sample walk by construction; the proof obligations are the inequalities above.
+struct SpanConst {
+    double base[3];      // 2 E + L * drift, rounded up
+    double lipd[3];      // L * |delT|, rounded up: metres per sample index
+    double half[3];      // box / 2
+    CountConst N;
+};
+
+__device__ __forceinline__ void axis_span(double half, float flo, float fhi, int nlo, int nhi, double map_res, double rf,
+                                          double bmin, double bmax, int key0, int dim, int (&k)[kAxisMax], bool& constant,
+                                          bool& surely_out) {
+    const double a0 = flo - half, a1 = fhi - half;          // xmin of PO.cpp:548 at both ends of the interval
+#pragma unroll
+    for (int i = 0; i < kAxisMax; ++i) {
+        k[i] = 0;
+        if (i <= nhi) {
+            const float q0 = (float)(a0 + i * map_res), q1 = (float)(a1 + i * map_res);
+            const bool both = q0 >= bmin && q0 <= bmax && q1 >= bmin && q1 <= bmax;     // false for NaN
+            const int k0 = (int)floor(rf * (double)q0) - key0, k1 = (int)floor(rf * (double)q1) - key0;
+            constant = constant && both && k0 == k1 && k0 >= 0 && k0 < dim;
+            if (i <= nlo) surely_out = surely_out || q1 < bmin || q0 > bmax || (both && (k1 < 0 || k0 >= dim));
+            k[i] = k0;
+        }
+    }
+}
+
+// 0: not certified, 1: every pose with floats in [flo, fhi] is free, 2: every such pose collides, 3: the keys are the same
+// for every such pose but the verdict depends on the pose's own lattice counts: *table holds it per choice of counts
+__device__ __forceinline__ int certify_span(const GridView& g, const SweepConst& C, const SpanConst& K, const float (&flo)[3],
+                                            const float (&fhi)[3], const Tile* T, const uint32_t* tile_words, int* table) {
+    int kx[kAxisMax], ky[kAxisMax], kz[kAxisMax];
+    bool constant = true, out = false;
+    axis_span(K.half[0], flo[0], fhi[0], K.N.nlo[0], K.N.nhi[0], C.map_res, C.rf, g.bmin[0], g.bmax[0], g.key0[0], g.nx, kx, constant, out);
+    axis_span(K.half[1], flo[1], fhi[1], K.N.nlo[1], K.N.nhi[1], C.map_res, C.rf, g.bmin[1], g.bmax[1], g.key0[1], g.ny, ky, constant, out);
+    axis_span(K.half[2], flo[2], fhi[2], K.N.nlo[2], K.N.nhi[2], C.map_res, C.rf, g.bmin[2], g.bmax[2], g.key0[2], g.nz, kz, constant, out);
+    if (out) return 2;
+    if (!constant) return 0;
+    const unsigned tt = lattice_any_all(g, T, tile_words, kx, ky, kz, K.N);
+    if (tt == 0u) return 1;
+    if (tt == 0xffu) return 2;          // (the OR is monotone in the counts: the all-nlo choice collides, so does every other)
+    *table = (int)tt;
+    return 3;
+}
+
+constexpr int kItemCap = 4 * kBlock;   // quarters of the spans of one batch: cannot overflow
+constexpr int kParallelMax = 2 * kBlock;
+
+// Two passes, one launch each (PASS 0 then PASS 1), so that neither carries the other's registers:
+//   PASS 0  segments of more than 512 samples by certified spans, shorter ones a sample per lane (both need the clock
+//           table).  A segment it cannot take — degenerate delT, a box of more than 3 map cells per axis, non-finite
+//           coefficients, samples further apart than 1/32 of a voxel, an exact-power queue that overflowed — is left to
+//           PASS 1 through A.todo[s];
+//   PASS 1  the walk of rounds 1-2 for those: every thread over chunks of 16 consecutive samples.
+// DEG7: the planner's degree (cfg polynomial_degree: 7), unrolled.
+// (four waves per SIMD = at most 128 VGPRs)
+#ifndef VIGO_CORRIDOR_WPS
+#define VIGO_CORRIDOR_WPS 4
+#endif
+template <int PASS, bool DEG7>
+__global__ void __launch_bounds__(kBlock, VIGO_CORRIDOR_WPS) k_corridor(GridView g, CorridorArgs A) {
     extern __shared__ __align__(16) uint32_t tile_words[];
     __shared__ double cf[3 * (kMaxDeg + 1)];
     __shared__ int s_min[3], s_max[3];
     __shared__ double s_err[3];
     __shared__ int s_first, s_count;
     __shared__ int q_n, q_idx[kQueueCap];          // samples the float filter could not certify
+    __shared__ ClockTable s_clock;
+    __shared__ double s_bern[3][kMaxDeg + 1], s_dbern[3][kMaxDeg + 1];
+    __shared__ SpanConst s_span;
+    __shared__ int s_span_ok[3];
+    __shared__ int s_items[kItemCap], s_in;          // quarters of spans that were not certified
+    __shared__ uint32_t s_bits[kBlock];              // one bit per sample of a batch: goes through the per-sample path
+    __shared__ uint32_t s_fbits[kBlock];             // ... : the verdict is s_tt at the pose's own lattice counts
+    __shared__ uint8_t s_tt[4 * kBlock];             // per quarter span: verdict for each of the 8 choices of counts
 
     const int s = blockIdx.x;
     if (s >= A.S) return;
+    if (PASS == 1 && !A.todo[s]) return;
     const int tid = threadIdx.x;
-    const int deg = A.deg;
+    const int deg = DEG7 ? 7 : A.deg;
     const int n = A.n_samp[s];
     const double dT = A.delT[s];
 
@@ -319,39 +512,106 @@ __global__ void __launch_bounds__(kBlock, 4) k_corridor(GridView g, CorridorArgs
         const int ax = tid / (deg + 1), d = tid % (deg + 1);
         cf[ax * (kMaxDeg + 1) + d] = A.coeffs[((size_t)s * 3 + ax) * (deg + 1) + d];
     }
-    if (tid < 3) { s_min[tid] = 0x7fffffff; s_max[tid] = (int)0x80000000; }
-    if (tid == 0) { s_first = 0x7fffffff; s_count = 0; q_n = 0; }
+    if (tid < 3) { s_min[tid] = 0x7fffffff; s_max[tid] = (int)0x80000000; s_err[tid] = 0.0; s_span_ok[tid] = 0; }
+    if (tid == 0) {
+        s_first = 0x7fffffff; s_count = 0; q_n = 0;
+        s_in = 0;
+        s_clock.n = -1;
+    }
     __syncthreads();
 
     const int n_chunks = (n + kChunk - 1) / kChunk;
 
-    // ---- bound of the sample positions: the Bernstein coefficients of the segment over [0, t_last]
-    //      (convex-hull property: min b_i <= p(t) <= max b_i) — three threads, 8 coefficients each,
-    //      instead of a pass over all samples.  The bound only sizes the LDS tile: a pose whose
-    //      lattice points fall outside the tile takes the L2 path in box_sweep, so results never
-    //      depend on it. ----
-    if (tid < 3) s_err[tid] = 0.0;
+    // ---- per-segment constants, spread over the block ----
+    //   clock   one lane of wave 3 writes the sample clock down as a table (vigo_exact_time.hpp);
+    //   bounds  the Bernstein coefficients of the segment and of its derivative over [0, Tu], one per thread of waves 0
+    //           and 1 (convex-hull property: min b_i <= p(t) <= max b_i), Tu >= every clock value — the accumulated
+    //           clock stays within n u of k delT, u = 2^-53.  The position bound only sizes the LDS tile: a pose whose
+    //           lattice points fall outside the tile takes the L2 path in box_sweep, so results never depend on it.  The
+    //           derivative bound is the Lipschitz constant of the span certificates (SpanConst).
+    const double Tu = n > 0 ? (double)(n - 1) * dT * (1.0 + 0x1p-20) : 0.0;
+    if (tid == 3 * 64 && n > 0) (void)build_clock_table(dT, n - 1, s_clock);
+    if (tid < 3 * (deg + 1)) {
+        const int a = tid / (deg + 1), i = tid % (deg + 1);
+        const double* c = cf + a * (kMaxDeg + 1);
+        // b_i = sum_{k <= i} C(i,k) / C(deg,k) * c_k * Tu^k
+        double bi = c[0], ratio = 1.0, pw = 1.0;
+        for (int k = 1; k <= i; ++k) {
+            ratio *= (double)(i - k + 1) / (double)(deg - k + 1);
+            pw *= Tu;
+            bi += ratio * c[k] * pw;
+        }
+        s_bern[a][i] = bi;
+    }
+    if (tid >= 64 && tid < 64 + 3 * deg) {
+        const int a = (tid - 64) / deg, i = (tid - 64) % deg;
+        const double* c = cf + a * (kMaxDeg + 1);
+        // the same for p' (coefficients (k + 1) c_{k+1}, degree deg - 1)
+        double bi = c[1], ratio = 1.0, pw = 1.0;
+        for (int k = 1; k <= i; ++k) {
+            ratio *= (double)(i - k + 1) / (double)(deg - k);
+            pw *= Tu;
+            bi += ratio * ((double)(k + 1) * c[k + 1]) * pw;
+        }
+        s_dbern[a][i] = fabs(bi);
+    }
+    __syncthreads();
     if (tid < 3 && n > 0) {
-        const double tl = accumulated_time(dT, n - 1);        // clock value of the last sample
         const double* c = cf + tid * (kMaxDeg + 1);
-        s_err[tid] = sampler_error_bound(c, deg, tl);         // filter of sample_f32()
+        s_err[tid] = sampler_error_bound(c, deg, Tu);         // filter of sample_f32()
         double lo = c[0], hi = c[0];                           // b_0 = c_0
-        // b_i = sum_{k <= i} C(i,k) / C(deg,k) * c_k * tl^k
         for (int i = 1; i <= deg; ++i) {
-            double bi = c[0], ratio = 1.0, pw = 1.0;
-            for (int k = 1; k <= i; ++k) {
-                ratio *= (double)(i - k + 1) / (double)(deg - k + 1);   // C(i,k)/C(deg,k)
-                pw *= tl;
-                bi += ratio * c[k] * pw;
-            }
-            lo = fmin(lo, bi);
-            hi = fmax(hi, bi);
+            lo = fmin(lo, s_bern[tid][i]);
+            hi = fmax(hi, s_bern[tid][i]);
         }
         const double pad = 1e-6 * (1.0 + fmax(fabs(lo), fabs(hi)));    // rounding of the conversion and of (float)p
         if (lo <= hi) {                                        // false for NaN coefficients
             s_min[tid] = f2ord((float)(lo - pad) - 1e-6f);
             s_max[tid] = f2ord((float)(hi + pad) + 1e-6f);
         }
+        // -- span certificates: Lipschitz constant of this axis, size of the positions, range of the lattice count
+        const double Tm = fabs(Tu);
+        double Ac = 0.0, A1 = 0.0, pwT = 1.0;                  // sum |c_d| T^d,  sum d |c_d| T^(d-1)
+        for (int d = 0; d <= deg; ++d) {
+            Ac += fabs(c[d]) * pwT;
+            if (d < deg) A1 += (double)(d + 1) * fabs(c[d + 1]) * pwT;
+            pwT *= Tm;
+        }
+        double Lb = 0.0;
+        for (int i = 0; i < deg; ++i) Lb = fmax(Lb, s_dbern[tid][i]);
+        const double L = Lb + 0x1p-40 * A1;                    // (rounding of the coefficients; NaN / inf: A1 carries them)
+        const double up = 1.0 + 0x1p-40;
+        const double drift = (double)n * 0x1p-52 * (Tm + fabs(dT));     // |t_k - fl(k delT)| for every k < n
+        const double base = (2.0 * s_err[tid] + L * drift) * up;
+        const double lipd = L * fabs(dT) * up;
+        const double h = A.sweep.box[tid] / 2;
+        const double Mx = Ac * (1.0 + 0x1p-20) + fabs(h);               // >= |(float)x| + |box / 2| for every sample
+        const double dl = 0x1p-50 * (Mx + fabs(h));                     // |(fx + h) - (fx - h) - box| as computed
+        double ql = (A.sweep.box[tid] - dl) / A.sweep.map_res, qh = (A.sweep.box[tid] + dl) / A.sweep.map_res;
+        ql -= fabs(ql) * 0x1p-50;
+        qh += fabs(qh) * 0x1p-50;
+        const bool ok = ql > -1.0 && qh < (double)kAxisMax && base < 1e300 && lipd < 1e300;   // false for NaN
+        s_span.base[tid] = base;
+        s_span.lipd[tid] = lipd;
+        s_span.half[tid] = h;
+        const int nlo = ok ? (int)ql : 0, nhi = ok ? (int)qh : 0;
+        // the dividing line of CountConst: the smallest d with (int)(d / map_res) >= nhi, a few ulps from nhi * map_res
+        double thr = -1.0;                                    // nlo == nhi: every difference reaches it
+        bool thr_ok = ok && nhi - nlo <= 1;
+        if (thr_ok && nhi != nlo) {
+            auto cnt = [&](double d) { return (int)(d / A.sweep.map_res); };
+            auto step = [](double d, int by) { return __longlong_as_double(__double_as_longlong(d) + by); };   // d > 0
+            double c = (double)nhi * A.sweep.map_res;
+            int guard = 0;
+            while (guard < 8 && cnt(step(c, -1)) >= nhi) { c = step(c, -1); ++guard; }
+            while (guard < 16 && cnt(c) < nhi) { c = step(c, 1); ++guard; }
+            thr_ok = cnt(c) >= nhi && cnt(step(c, -1)) < nhi;
+            thr = c;
+        }
+        s_span.N.nlo[tid] = nlo;
+        s_span.N.nhi[tid] = nhi;
+        s_span.N.thr[tid] = thr;
+        s_span_ok[tid] = ok ? (thr_ok ? 3 : 1) : 0;           // bit 0: span certificates, bit 1: counts by compare
     }
     __syncthreads();
 
@@ -393,31 +653,215 @@ __global__ void __launch_bounds__(kBlock, 4) k_corridor(GridView g, CorridorArgs
     }
     __syncthreads();
 
-    // ---- sweep pass: box sweep per sample ----
+    // ---- how the samples are visited (block-uniform) ----
+    // PASS 0 takes a segment when it has a clock table and its lattice counts go by compare (CountConst):
+    //   certify  n > 512 and samples closer than 1/32 of a voxel: certified spans of 32 or 16 samples, cut in four
+    //            where the certificate fails (see SpanConst);
+    //   else     n <= 512: every sample through the per-sample path, a lane each.
+    // Everything else — degenerate delT, a box of more than 3 map cells per axis, non-finite coefficients, fast or very
+    // long segments, an exact-power queue that overflows — is PASS 1's: the walk of rounds 1-2, every thread over chunks
+    // of 16 consecutive samples.
+    const bool table = s_clock.n > 0;
+    const bool counts = (s_span_ok[0] & s_span_ok[1] & s_span_ok[2] & 2) != 0;
+    int S1 = 0;
+    if (n > kParallelMax && n <= (1 << 24)) {
+        const double lipmax = fmax(s_span.lipd[0], fmax(s_span.lipd[1], s_span.lipd[2]));
+        const double cell = 0.25 / A.sweep.rf;                // a quarter of a voxel: the reach of a span's certificate
+        S1 = lipmax * 16.0 <= cell ? 32 : lipmax * 8.0 <= cell ? 16 : 0;
+    }
+    const bool certify = S1 > 0;
+    if (PASS == 0) {
+        const bool mine = table && counts && (certify || n <= kParallelMax);
+        if (tid == 0) A.todo[s] = mine ? 0 : 1;
+        if (!mine) return;
+        if (!certify) S1 = 32;
+    }
+
     int my_first = 0x7fffffff, my_count = 0;
-    SweepMemo memo;
-    memo.nums = -1;
-    memo.verdict = false;
-#pragma unroll
-    for (int i = 0; i < kAxisMax; ++i) memo.kx[i] = memo.ky[i] = memo.kz[i] = 0;
     // (block-uniform: kept in SGPRs — six VGPRs more would cost the kernel its fourth wave per SIMD)
     const double E[3] = {uniform_f64(s_err[0]), uniform_f64(s_err[1]), uniform_f64(s_err[2])};
     {
-        // the planner's degree (cfg polynomial_degree: 7) keeps its coefficients in registers
+        // PASS 1 keeps the coefficients of the planner's degree in registers; PASS 0 reads them from LDS
+        constexpr bool REG = PASS == 1;
         double c7[3][8];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int d = 0; d < 8; ++d) c7[a][d] = deg == 7 ? cf[a * (kMaxDeg + 1) + d] : 0.0;
-        auto walk = [&](auto deg7_tag) {
-            constexpr bool DEG7 = decltype(deg7_tag)::value;
+            for (int d = 0; d < 8; ++d) c7[a][d] = (DEG7 && REG) ? cf[a * (kMaxDeg + 1) + d] : 0.0;
+        // the lattice counts by compare where the segment's constants allow it (CountConst), block-uniform
+        CountConst Nc;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            Nc.nlo[a] = __builtin_amdgcn_readfirstlane(s_span.N.nlo[a]);
+            Nc.nhi[a] = __builtin_amdgcn_readfirstlane(s_span.N.nhi[a]);
+            Nc.thr[a] = uniform_f64(s_span.N.thr[a]);
+        }
+        if constexpr (PASS == 0) {
+            SpanConst K;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                K.base[a] = uniform_f64(s_span.base[a]);
+                K.lipd[a] = uniform_f64(s_span.lipd[a]);
+                K.half[a] = uniform_f64(s_span.half[a]);
+            }
+            K.N = Nc;
+            // Batches of up to kBlock spans of S1 samples (S1 = 32 or 16: a span is one word of the bit maps or half of one).
+            //   1  a lane per span: certificate, else its four quarters queued (a segment that is not certified at all:
+            //      its samples marked in s_bits);
+            //   2  a lane per queued quarter: certificate, else its samples marked in s_bits;
+            //      (1, 2: a span whose keys are constant but whose verdict hangs on each pose's own lattice counts
+            //      is marked in s_fbits, with the verdict per choice of counts in s_tt)
+            //   3  the marked samples, compacted per wave (prefix sums over the words' popcounts), a lane per sample:
+            //      s_bits through the whole per-sample path, s_fbits through the sampler, the three counts and s_tt.
+            const int wave = tid >> 6, lane = tid & 63;
+            const int q_len = S1 >> 2, q_shift = S1 == 32 ? 3 : 2;
+            int k_base = 0;
+            auto mask_of = [&](int k0, int len) { return (len >= 32 ? 0xffffffffu : ((1u << len) - 1u)) << ((k0 - k_base) & 31); };
+            auto mark = [&](int k0, int len) { atomicOr(&s_bits[(k0 - k_base) >> 5], mask_of(k0, len)); };
+            auto mark_counts = [&](int k0, int len, int tt) {
+                atomicOr(&s_fbits[(k0 - k_base) >> 5], mask_of(k0, len));
+                for (int o = 0; o < len; o += q_len) s_tt[(k0 + o - k_base) >> q_shift] = (uint8_t)tt;
+            };
+            // certificate of one span: 1 decided and accounted for, 3 marked in s_fbits, 0 open
+            auto decide = [&](int k0, int len) -> int {
+                const int c = k0 + (len >> 1);
+                const int hs = max(c - k0, k0 + len - 1 - c);
+                const double ts = fmin(fmax((double)c * dT, 0.0), Tu);   // a clock value within reach of the span (delT > 0 here)
+                double p[3];
+                if (DEG7) poly_fast7_lds(cf, ts, p);
+                else poly_fast(cf, deg, ts, p);
+                float flo[3], fhi[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double R = (K.base[a] + K.lipd[a] * (double)hs) * (1.0 + 0x1p-40);
+                    flo[a] = (float)(p[a] - R);
+                    fhi[a] = (float)(p[a] + R);
+                }
+                int tt = 0;
+                const int v = certify_span(g, A.sweep, K, flo, fhi, &T, tile_words, &tt);
+                if (v == 2) {
+                    if (k0 < my_first) my_first = k0;
+                    my_count += len;
+                }
+                if (v == 3) mark_counts(k0, len, tt);
+                return v == 2 ? 1 : v;
+            };
+            const int n_spans = (n + S1 - 1) / S1;
+            const int n_batches = (n_spans + kBlock - 1) / kBlock;
+            const int per_batch = (n_spans + n_batches - 1) / n_batches;  // <= kBlock spans, the batches alike
+            for (int base = 0; base < n_spans; base += per_batch) {     // block-uniform trip count
+                k_base = base * S1;
+                s_bits[tid] = 0u;
+                s_fbits[tid] = 0u;
+                if (tid == 0) s_in = 0;
+                __syncthreads();
+#pragma unroll 1
+                for (int phase = 0; phase < 2; ++phase) {               // 1: the batch's spans, 2: the queued quarters
+                    const int cnt = phase == 0 ? min(per_batch, n_spans - base) : s_in;
+                    for (int i = tid; i < cnt; i += kBlock) {
+                        int k0, len;
+                        if (phase == 0) {
+                            k0 = (base + i) * S1;
+                            len = min(S1, n - k0);
+                        } else {
+                            const int it = s_items[i];
+                            k0 = it >> 6;
+                            len = it & 63;
+                        }
+                        if (!certify) mark(k0, len);
+                        else if (decide(k0, len) == 0) {
+                            if (phase == 1 || len <= q_len) mark(k0, len);
+                            else {
+                                for (int o = 0; o < len; o += q_len) {
+                                    const int slot = atomicAdd(&s_in, 1);             // < kItemCap by construction
+                                    s_items[slot] = ((k0 + o) << 6) | min(q_len, len - o);
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+                // the marked samples of both bit maps, a lane each: lane j of wave w takes word 4 j + w, so that every
+                // wave sees the whole batch at a stride of four words
+#pragma unroll 1
+                for (int which = 0; which < 2; ++which) {
+                    const uint32_t* bits = which ? s_fbits : s_bits;
+                    const uint32_t W = bits[lane * 4 + wave];
+                    const int cw = __popc(W);
+                    // (the clock table's piece at the word's first sample, looked up once per word: its samples start there)
+                    const int piece_w = W ? clock_piece(s_clock, k_base + ((lane * 4 + wave) << 5)) : 0;
+                    int incl = cw;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const int up = __shfl_up(incl, d);
+                        if (lane >= d) incl += up;
+                    }
+                    const int total = __shfl(incl, 63), excl = incl - cw;
+#pragma unroll 1
+                    for (int r0 = 0; r0 < total; r0 += 64) {
+                        const int r = r0 + lane;
+                        int L = 0;                                       // the first lane whose inclusive count exceeds r
+#pragma unroll
+                        for (int st = 32; st >= 1; st >>= 1)
+                            if (__shfl(incl, L + st - 1) <= r) L += st;
+                        L = min(L, 63);
+                        const uint32_t WL = __shfl(W, L);
+                        int rr = r - __shfl(excl, L), pos = 0;          // the rr-th set bit of that lane's word
+#pragma unroll
+                        for (int st = 16; st >= 1; st >>= 1) {
+                            const int below = __popc((WL >> pos) & ((1u << st) - 1u));
+                            if (rr >= below) { rr -= below; pos += st; }
+                        }
+                        const int piece = __shfl(piece_w, L);
+                        if (r < total) {
+                            const int k = k_base + ((L * 4 + wave) << 5) + pos;
+                            const double t = clock_from(s_clock, piece, k);
+                            float f[3];
+                            if (sample_f32_fast<DEG7, false>(c7, cf, deg, t, E, f)) {    // pose2Octomap of getPose(t), certified
+                                bool hit;
+                                if (which == 0) hit = box_sweep_fast(g, A.sweep, Nc, f[0], f[1], f[2], &T, tile_words);
+                                else {
+                                    // the three lattice counts of this pose (box_sweep's own expressions) pick the verdict
+                                    int idx = 0;
+#pragma unroll
+                                    for (int a = 0; a < 3; ++a) {
+                                        const double lo = f[a] - K.half[a], hi = f[a] + K.half[a];
+                                        if ((hi - lo) >= Nc.thr[a]) idx |= 1 << a;
+                                    }
+                                    hit = ((s_tt[(k - k_base) >> q_shift] >> idx) & 1) != 0;
+                                }
+                                if (hit) {
+                                    if (k < my_first) my_first = k;
+                                    ++my_count;
+                                }
+                            } else {
+                                const int slot = atomicAdd(&q_n, 1);
+                                if (slot < kQueueCap) q_idx[slot] = k;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (q_n > kQueueCap) {          // the exact-power queue overflowed: the second pass starts over
+                if (tid == 0) A.todo[s] = 1;
+                return;
+            }
+        } else {
+            const CountConst* Np = counts ? &Nc : nullptr;
+            // every lane remembers the keys and verdict of its previous pose (SweepMemo)
+            SweepMemo memo;
+            memo.nums = -1;
+            memo.verdict = false;
+#pragma unroll
+            for (int i = 0; i < kAxisMax; ++i) memo.kx[i] = memo.ky[i] = memo.kz[i] = 0;
             for (int c = tid; c < n_chunks; c += kBlock) {
                 const int k0 = c * kChunk, k1 = min(n, k0 + kChunk);
-                double t = accumulated_time(dT, k0);
+                double t = table ? clock_at(s_clock, k0) : accumulated_time(dT, k0);
                 for (int k = k0; k < k1; ++k) {
                     float f[3];
-                    if (sample_f32_fast<DEG7>(c7, cf, deg, t, E, f)) {    // pose2Octomap of getPose(t), certified
-                        if (box_sweep(g, A.sweep, f[0], f[1], f[2], &T, tile_words, &memo)) {
+                    if (sample_f32_fast<DEG7, true>(c7, cf, deg, t, E, f)) {    // pose2Octomap of getPose(t), certified
+                        if (box_sweep(g, A.sweep, f[0], f[1], f[2], &T, tile_words, &memo, Np)) {
                             if (k < my_first) my_first = k;
                             ++my_count;
                         }
@@ -428,31 +872,27 @@ __global__ void __launch_bounds__(kBlock, 4) k_corridor(GridView g, CorridorArgs
                     t += dT;
                 }
             }
-        };
-        if (deg == 7) walk(std::true_type{});
-        else walk(std::false_type{});
+        }
     }
     __syncthreads();
     // ---- the queued samples, with the exact-power chain.  A queue that overflowed (non-finite coefficients, a
     //      polynomial that cancels to ~0 over its whole span) is replaced by a walk over all samples that repeats
-    //      the filter and handles exactly those it rejects — the same set. ----
+    //      the filter and handles exactly those it rejects — the same set.  (PASS 1 only: PASS 0 has handed such a
+    //      segment over.) ----
     {
         const int queued = q_n;
-        auto exact_one = [&](int k) {
+        const bool all = PASS == 1 && queued > kQueueCap;
+        const int count = all ? n : queued;
+        const double c0[3][8] = {};
+        for (int i = tid; i < count; i += kBlock) {
+            const int k = all ? i : q_idx[i];
+            const double t = accumulated_time(dT, k);
             float f[3];
-            sample_f32_exact(cf, deg, accumulated_time(dT, k), f);
+            if (all && sample_f32_fast<false>(c0, cf, deg, t, E, f)) continue;
+            sample_f32_exact(cf, deg, t, f);
             if (box_sweep(g, A.sweep, f[0], f[1], f[2], &T, tile_words, nullptr)) {
                 if (k < my_first) my_first = k;
                 ++my_count;
-            }
-        };
-        if (queued <= kQueueCap) {
-            for (int i = tid; i < queued; i += kBlock) exact_one(q_idx[i]);
-        } else {
-            const double c0[3][8] = {};
-            for (int k = tid; k < n; k += kBlock) {
-                float f[3];
-                if (!sample_f32_fast<false>(c0, cf, deg, accumulated_time(dT, k), E, f)) exact_one(k);
             }
         }
     }
@@ -674,18 +1114,25 @@ int launch_esdf_brick(hipStream_t s, int nx, int ny, int nz, const float* src, f
     return (int)hipGetLastError();
 }
 
-int launch_corridor_check(hipStream_t s, const GridView& g, int S, int deg, const double* coeffs,
+int launch_corridor_check2(hipStream_t s, const GridView& g, int S, int deg, const double* coeffs,
                           const int32_t* n_samp, const double* delT, const double box[3],
-                          double map_res, uint8_t* out_flag, int32_t* out_first, int32_t* out_count) {
+                          double map_res, uint8_t* out_flag, int32_t* out_first, int32_t* out_count, int* todo) {
     if (S <= 0) return hipSuccess;
     CorridorArgs A{};
     A.S = S; A.deg = deg;
     A.coeffs = coeffs; A.n_samp = n_samp; A.delT = delT;
     A.sweep = SweepConst{{box[0], box[1], box[2]}, map_res, 1.0 / g.res};
     A.out_flag = out_flag; A.out_first = out_first; A.out_count = out_count;
-    const int tile_bytes = 32 * 1024;
+    const int tile_bytes = 27 * 1024;         // with the kernel's static LDS (12.9 KB): four workgroups per CU
     A.tile_words_cap = tile_bytes / 4;
-    hipLaunchKernelGGL(k_corridor, dim3(S), dim3(kBlock), tile_bytes, s, g, A);
+    A.todo = todo;
+    if (deg == 7) {
+        hipLaunchKernelGGL((k_corridor<0, true>), dim3(S), dim3(kBlock), tile_bytes, s, g, A);
+        hipLaunchKernelGGL((k_corridor<1, true>), dim3(S), dim3(kBlock), tile_bytes, s, g, A);
+    } else {
+        hipLaunchKernelGGL((k_corridor<0, false>), dim3(S), dim3(kBlock), tile_bytes, s, g, A);
+        hipLaunchKernelGGL((k_corridor<1, false>), dim3(S), dim3(kBlock), tile_bytes, s, g, A);
+    }
     return (int)hipGetLastError();
 }
 

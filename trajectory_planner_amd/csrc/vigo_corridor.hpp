@@ -1,0 +1,15 @@
+// vigo_corridor.hpp — launcher of the corridor checker's two passes (vigo_corridor.hip, k_corridor).
+// Supersedes launch_corridor_check() as declared in vigo_internal.hpp: that declaration has no work list and is left
+// there only because vigo_internal.hpp is part of the solve kernels' build id (profiles/pmc_*.json are tied to it).
+#pragma once
+
+#include "vigo_internal.hpp"
+
+namespace vigo {
+
+// todo: S ints of device scratch (which segments the first pass left to the second)
+int launch_corridor_check2(hipStream_t s, const GridView& g, int S, int deg, const double* coeffs, const int32_t* n_samp,
+                           const double* delT, const double box[3], double map_res, uint8_t* out_flag, int32_t* out_first,
+                           int32_t* out_count, int* todo);
+
+}  // namespace vigo
