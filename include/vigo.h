@@ -366,6 +366,16 @@ int vigo_minsnap(vigo_handle_t h, int T, int W, int deg, int diff, int cont, dou
  *   box[3], map_res               collision_box / map_resolution (cfg/planner_interactive.yaml)
  *   out_flag uint8[S]; out_first int32[S] first colliding sample index or -1;
  *   out_count int32[S] number of colliding samples (may be NULL)
+ * Every sample's verdict is the reference walk's; how they are reached is not (csrc/vigo_corridor.hip): segments of
+ * more than 512 samples are cut into spans of 32 or 16 samples, and a span is decided by ONE evaluation when the kernel
+ * can prove that all its samples see the same voxel keys (an interval that holds every sample's float position, taken
+ * through the reference's own monotone expressions at both ends); spans it cannot decide are cut in four, and what
+ * remains goes through the per-sample sweep.  The accumulated clock t += delT is reproduced exactly
+ * (vigo_accumulated_time / vigo_clock_table_time below).
+ * A pose at NaN or infinity (non-finite coefficients, overflow to float): the reference's lattice count
+ * (int)((xmax - xmin) / map_res) is then the conversion of a NaN — undefined in C++, INT_MIN on x86, where the sweep
+ * makes no pass and the pose does NOT collide.  Both entry points below follow x86 (the oracle on this host does);
+ * a caller that wants such poses refused tests them itself (the host facade does: host/src/polyTrajOctomap.cpp).
  */
 int vigo_corridor_check(vigo_handle_t h, int S, int deg, const double* coeffs,
                         const int32_t* n_samp, const double* delT,

@@ -1123,7 +1123,8 @@ int launch_corridor_check2(hipStream_t s, const GridView& g, int S, int deg, con
     A.coeffs = coeffs; A.n_samp = n_samp; A.delT = delT;
     A.sweep = SweepConst{{box[0], box[1], box[2]}, map_res, 1.0 / g.res};
     A.out_flag = out_flag; A.out_first = out_first; A.out_count = out_count;
-    const int tile_bytes = 27 * 1024;         // with the kernel's static LDS (12.9 KB): four workgroups per CU
+    // with the first pass' static LDS (12.9 KB): VIGO_CORRIDOR_WPS workgroups per CU (27 KB of tile for four)
+    const int tile_bytes = (160 * 1024 / VIGO_CORRIDOR_WPS - 13 * 1024) & ~255;
     A.tile_words_cap = tile_bytes / 4;
     A.todo = todo;
     if (deg == 7) {

@@ -119,6 +119,12 @@ bool polyTrajOctomap::sweepPoints(const std::vector<pose>& pts, std::vector<uint
     const double box[3] = {collisionBox_[0], collisionBox_[1], collisionBox_[2]};
     ok = ok && vigo_box_collision_points(dev_, (int64_t)pts.size(), (const double*)dP.p, box, mapRes_, (uint8_t*)dF.p) == VIGO_OK;
     ok = ok && dF.download(flags.data(), pts.size());
+    // A pose at NaN or infinity: the reference's sweep makes no pass there (the lattice count is the conversion of a
+    // NaN, INT_MIN on x86 — the device entry point follows that, include/vigo.h) and would publish the trajectory.  The
+    // facade refuses such a pose instead: a degenerate min-snap solution (coincident waypoints) then falls back to the
+    // piecewise-linear plan like any colliding one.
+    for (size_t i = 0; i < pts.size(); ++i)
+        if (!(std::isfinite(pts[i].x) && std::isfinite(pts[i].y) && std::isfinite(pts[i].z))) flags[i] = 1;
     if (!ok && dev_) cout << "[Trajectory Planner INFO]: device box sweep failed: " << vigo_last_error(dev_) << endl;
     return ok;
 }
@@ -418,6 +424,8 @@ std::vector<bool> polyTrajOctomap::makePlanBatch(const std::vector<polyTrajOctom
                  vigo_box_collision_points(lead->dev_, (int64_t)M, (const double*)bPts.p, box, lead->mapRes_, (uint8_t*)bFl.p) == VIGO_OK &&
                  bFl.download(flags.data(), M);
             if (!ok) break;
+            for (size_t k = 0; k < M; ++k)             // a pose at NaN or infinity is refused (see sweepPoints)
+                if (!(std::isfinite(pts[3 * k]) && std::isfinite(pts[3 * k + 1]) && std::isfinite(pts[3 * k + 2]))) flags[k] = 1;
         }
         for (int a = 0; a < T; ++a) {
             const size_t g = act[a];
