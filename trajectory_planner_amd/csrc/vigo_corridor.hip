@@ -469,7 +469,9 @@ __device__ __forceinline__ int certify_span(const GridView& g, const SweepConst&
     return 3;
 }
 
-constexpr int kItemCap = 4 * kBlock;   // quarters of the spans of one batch: cannot overflow
+constexpr int kItemCap = 4 * kBlock;   // pieces waiting for their certificate, per level (a full queue marks samples instead)
+constexpr int kBitWords = 2 * kBlock;  // a batch: up to kBlock spans of up to 64 samples
+constexpr int kTtBytes = 16 * kBlock;  // the smallest pieces are a sixteenth of a span
 constexpr int kParallelMax = 2 * kBlock;
 
 // Two passes, one launch each (PASS 0 then PASS 1), so that neither carries the other's registers:
@@ -495,10 +497,10 @@ __global__ void __launch_bounds__(kBlock, VIGO_CORRIDOR_WPS) k_corridor(GridView
     __shared__ double s_bern[3][kMaxDeg + 1], s_dbern[3][kMaxDeg + 1];
     __shared__ SpanConst s_span;
     __shared__ int s_span_ok[3];
-    __shared__ int s_items[kItemCap], s_in;          // quarters of spans that were not certified
-    __shared__ uint32_t s_bits[kBlock];              // one bit per sample of a batch: goes through the per-sample path
-    __shared__ uint32_t s_fbits[kBlock];             // ... : the verdict is s_tt at the pose's own lattice counts
-    __shared__ uint8_t s_tt[4 * kBlock];             // per quarter span: verdict for each of the 8 choices of counts
+    __shared__ int s_items[2][kItemCap], s_in[2];    // pieces of spans that were not certified, two levels of cutting
+    __shared__ uint32_t s_bits[kBitWords];           // one bit per sample of a batch: goes through the per-sample path
+    __shared__ uint32_t s_fbits[kBitWords];          // ... : the verdict is s_tt at the pose's own lattice counts
+    __shared__ uint8_t s_tt[kTtBytes];               // per smallest piece: verdict for each of the 8 choices of counts
 
     const int s = blockIdx.x;
     if (s >= A.S) return;
@@ -515,7 +517,6 @@ __global__ void __launch_bounds__(kBlock, VIGO_CORRIDOR_WPS) k_corridor(GridView
     if (tid < 3) { s_min[tid] = 0x7fffffff; s_max[tid] = (int)0x80000000; s_err[tid] = 0.0; s_span_ok[tid] = 0; }
     if (tid == 0) {
         s_first = 0x7fffffff; s_count = 0; q_n = 0;
-        s_in = 0;
         s_clock.n = -1;
     }
     __syncthreads();
@@ -667,7 +668,7 @@ __global__ void __launch_bounds__(kBlock, VIGO_CORRIDOR_WPS) k_corridor(GridView
     if (n > kParallelMax && n <= (1 << 24)) {
         const double lipmax = fmax(s_span.lipd[0], fmax(s_span.lipd[1], s_span.lipd[2]));
         const double cell = 0.25 / A.sweep.rf;                // a quarter of a voxel: the reach of a span's certificate
-        S1 = lipmax * 16.0 <= cell ? 32 : lipmax * 8.0 <= cell ? 16 : 0;
+        S1 = lipmax * 32.0 <= cell ? 64 : lipmax * 16.0 <= cell ? 32 : lipmax * 8.0 <= cell ? 16 : 0;
     }
     const bool certify = S1 > 0;
     if (PASS == 0) {
@@ -705,28 +706,32 @@ __global__ void __launch_bounds__(kBlock, VIGO_CORRIDOR_WPS) k_corridor(GridView
                 K.half[a] = uniform_f64(s_span.half[a]);
             }
             K.N = Nc;
-            // Batches of up to kBlock spans of S1 samples (S1 = 32 or 16: a span is one word of the bit maps or half of one).
-            //   1  a lane per span: certificate, else its four quarters queued (a segment that is not certified at all:
-            //      its samples marked in s_bits);
-            //   2  a lane per queued quarter: certificate, else its samples marked in s_bits;
-            //      (1, 2: a span whose keys are constant but whose verdict hangs on each pose's own lattice counts
-            //      is marked in s_fbits, with the verdict per choice of counts in s_tt)
-            //   3  the marked samples, compacted per wave (prefix sums over the words' popcounts), a lane per sample:
+            // Batches of up to kBlock spans of S1 samples (64, 32 or 16), three rounds of certificates and the rest:
+            //   1  a lane per span: certificate, else its four quarters queued;
+            //   2  a lane per queued quarter: certificate, else ITS quarters queued;
+            //   3  a lane per queued sixteenth: certificate, else its samples marked in s_bits;
+            //      (a piece of 2 samples or fewer is not queued but marked; so is one that finds its queue full.  A piece
+            //      whose keys are constant but whose verdict hangs on each pose's own lattice counts is marked in
+            //      s_fbits, with the verdict per choice of counts in s_tt)
+            //   4  the marked samples, compacted per wave (prefix sums over the words' popcounts), a lane per sample:
             //      s_bits through the whole per-sample path, s_fbits through the sampler, the three counts and s_tt.
             const int wave = tid >> 6, lane = tid & 63;
-            const int q_len = S1 >> 2, q_shift = S1 == 32 ? 3 : 2;
+            const int g_shift = S1 == 64 ? 2 : S1 == 32 ? 1 : 2;       // log2 of the smallest piece: 4, 2, 4 samples
             int k_base = 0;
-            auto mask_of = [&](int k0, int len) { return (len >= 32 ? 0xffffffffu : ((1u << len) - 1u)) << ((k0 - k_base) & 31); };
-            auto mark = [&](int k0, int len) { atomicOr(&s_bits[(k0 - k_base) >> 5], mask_of(k0, len)); };
-            auto mark_counts = [&](int k0, int len, int tt) {
-                atomicOr(&s_fbits[(k0 - k_base) >> 5], mask_of(k0, len));
-                for (int o = 0; o < len; o += q_len) s_tt[(k0 + o - k_base) >> q_shift] = (uint8_t)tt;
+            auto mark_in = [&](uint32_t* bits, int k0, int len) {
+                int b = k0 - k_base;
+                while (len > 0) {
+                    const int take = min(len, 32 - (b & 31));
+                    atomicOr(&bits[b >> 5], (take >= 32 ? 0xffffffffu : ((1u << take) - 1u)) << (b & 31));
+                    b += take;
+                    len -= take;
+                }
             };
-            // certificate of one span: 1 decided and accounted for, 3 marked in s_fbits, 0 open
+            // certificate of one piece: 1 decided and accounted for, 3 marked in s_fbits, 0 open
             auto decide = [&](int k0, int len) -> int {
                 const int c = k0 + (len >> 1);
                 const int hs = max(c - k0, k0 + len - 1 - c);
-                const double ts = fmin(fmax((double)c * dT, 0.0), Tu);   // a clock value within reach of the span (delT > 0 here)
+                const double ts = fmin(fmax((double)c * dT, 0.0), Tu);   // a clock value within reach of the piece (delT > 0 here)
                 double p[3];
                 if (DEG7) poly_fast7_lds(cf, ts, p);
                 else poly_fast(cf, deg, ts, p);
@@ -743,100 +748,110 @@ __global__ void __launch_bounds__(kBlock, VIGO_CORRIDOR_WPS) k_corridor(GridView
                     if (k0 < my_first) my_first = k0;
                     my_count += len;
                 }
-                if (v == 3) mark_counts(k0, len, tt);
+                if (v == 3) {
+                    mark_in(s_fbits, k0, len);
+                    for (int o = 0; o < len; o += 1 << g_shift) s_tt[(k0 + o - k_base) >> g_shift] = (uint8_t)tt;
+                }
                 return v == 2 ? 1 : v;
             };
             const int n_spans = (n + S1 - 1) / S1;
             const int n_batches = (n_spans + kBlock - 1) / kBlock;
             const int per_batch = (n_spans + n_batches - 1) / n_batches;  // <= kBlock spans, the batches alike
+            const int n_words = (per_batch * S1 + 31) >> 5;              // <= kBitWords
             for (int base = 0; base < n_spans; base += per_batch) {     // block-uniform trip count
                 k_base = base * S1;
-                s_bits[tid] = 0u;
-                s_fbits[tid] = 0u;
-                if (tid == 0) s_in = 0;
+                for (int w = tid; w < n_words; w += kBlock) { s_bits[w] = 0u; s_fbits[w] = 0u; }
+                if (tid < 2) s_in[tid] = 0;
                 __syncthreads();
 #pragma unroll 1
-                for (int phase = 0; phase < 2; ++phase) {               // 1: the batch's spans, 2: the queued quarters
-                    const int cnt = phase == 0 ? min(per_batch, n_spans - base) : s_in;
+                for (int phase = 0; phase < 3; ++phase) {
+                    const int cnt = phase == 0 ? min(per_batch, n_spans - base) : min(s_in[(phase - 1) & 1], kItemCap);
+                    const int child = (S1 >> 2) >> (2 * phase);             // a quarter of this round's pieces
                     for (int i = tid; i < cnt; i += kBlock) {
                         int k0, len;
                         if (phase == 0) {
                             k0 = (base + i) * S1;
                             len = min(S1, n - k0);
                         } else {
-                            const int it = s_items[i];
-                            k0 = it >> 6;
-                            len = it & 63;
+                            const int it = s_items[(phase - 1) & 1][i];
+                            k0 = it >> 7;
+                            len = it & 127;
                         }
-                        if (!certify) mark(k0, len);
+                        if (!certify) mark_in(s_bits, k0, len);
                         else if (decide(k0, len) == 0) {
-                            if (phase == 1 || len <= q_len) mark(k0, len);
+                            if (phase == 2 || child < 2 || len <= child) mark_in(s_bits, k0, len);
                             else {
-                                for (int o = 0; o < len; o += q_len) {
-                                    const int slot = atomicAdd(&s_in, 1);             // < kItemCap by construction
-                                    s_items[slot] = ((k0 + o) << 6) | min(q_len, len - o);
+                                for (int o = 0; o < len; o += child) {
+                                    const int l = min(child, len - o);
+                                    const int slot = l > 2 ? atomicAdd(&s_in[phase & 1], 1) : kItemCap;
+                                    if (slot < kItemCap) s_items[phase & 1][slot] = ((k0 + o) << 7) | l;
+                                    else mark_in(s_bits, k0 + o, l);
                                 }
                             }
                         }
                     }
                     __syncthreads();
                 }
-                // the marked samples of both bit maps, a lane each: lane j of wave w takes word 4 j + w, so that every
-                // wave sees the whole batch at a stride of four words
+                // the marked samples of both bit maps, a lane each: in round r lane j of wave w takes word kBlock r + 4 j + w,
+                // so that every wave sees the whole batch at a stride of four words
 #pragma unroll 1
                 for (int which = 0; which < 2; ++which) {
                     const uint32_t* bits = which ? s_fbits : s_bits;
-                    const uint32_t W = bits[lane * 4 + wave];
-                    const int cw = __popc(W);
-                    // (the clock table's piece at the word's first sample, looked up once per word: its samples start there)
-                    const int piece_w = W ? clock_piece(s_clock, k_base + ((lane * 4 + wave) << 5)) : 0;
-                    int incl = cw;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const int up = __shfl_up(incl, d);
-                        if (lane >= d) incl += up;
-                    }
-                    const int total = __shfl(incl, 63), excl = incl - cw;
 #pragma unroll 1
-                    for (int r0 = 0; r0 < total; r0 += 64) {
-                        const int r = r0 + lane;
-                        int L = 0;                                       // the first lane whose inclusive count exceeds r
+                    for (int w0 = 0; w0 < n_words; w0 += kBlock) {
+                        const int my_word = w0 + lane * 4 + wave;
+                        const uint32_t W = my_word < n_words ? bits[my_word] : 0u;
+                        const int cw = __popc(W);
+                        // (the clock table's piece at the word's first sample, looked up once per word: its samples start there)
+                        const int piece_w = W ? clock_piece(s_clock, k_base + (my_word << 5)) : 0;
+                        int incl = cw;
 #pragma unroll
-                        for (int st = 32; st >= 1; st >>= 1)
-                            if (__shfl(incl, L + st - 1) <= r) L += st;
-                        L = min(L, 63);
-                        const uint32_t WL = __shfl(W, L);
-                        int rr = r - __shfl(excl, L), pos = 0;          // the rr-th set bit of that lane's word
-#pragma unroll
-                        for (int st = 16; st >= 1; st >>= 1) {
-                            const int below = __popc((WL >> pos) & ((1u << st) - 1u));
-                            if (rr >= below) { rr -= below; pos += st; }
+                        for (int d = 1; d < 64; d <<= 1) {
+                            const int up = __shfl_up(incl, d);
+                            if (lane >= d) incl += up;
                         }
-                        const int piece = __shfl(piece_w, L);
-                        if (r < total) {
-                            const int k = k_base + ((L * 4 + wave) << 5) + pos;
-                            const double t = clock_from(s_clock, piece, k);
-                            float f[3];
-                            if (sample_f32_fast<DEG7, false>(c7, cf, deg, t, E, f)) {    // pose2Octomap of getPose(t), certified
-                                bool hit;
-                                if (which == 0) hit = box_sweep_fast(g, A.sweep, Nc, f[0], f[1], f[2], &T, tile_words);
-                                else {
-                                    // the three lattice counts of this pose (box_sweep's own expressions) pick the verdict
-                                    int idx = 0;
+                        const int total = __shfl(incl, 63), excl = incl - cw;
+#pragma unroll 1
+                        for (int r0 = 0; r0 < total; r0 += 64) {
+                            const int r = r0 + lane;
+                            int L = 0;                                       // the first lane whose inclusive count exceeds r
 #pragma unroll
-                                    for (int a = 0; a < 3; ++a) {
-                                        const double lo = f[a] - K.half[a], hi = f[a] + K.half[a];
-                                        if ((hi - lo) >= Nc.thr[a]) idx |= 1 << a;
+                            for (int st = 32; st >= 1; st >>= 1)
+                                if (__shfl(incl, L + st - 1) <= r) L += st;
+                            L = min(L, 63);
+                            const uint32_t WL = __shfl(W, L);
+                            int rr = r - __shfl(excl, L), pos = 0;          // the rr-th set bit of that lane's word
+#pragma unroll
+                            for (int st = 16; st >= 1; st >>= 1) {
+                                const int below = __popc((WL >> pos) & ((1u << st) - 1u));
+                                if (rr >= below) { rr -= below; pos += st; }
+                            }
+                            const int piece = __shfl(piece_w, L);
+                            if (r < total) {
+                                const int k = k_base + ((w0 + L * 4 + wave) << 5) + pos;
+                                const double t = clock_from(s_clock, piece, k);
+                                float f[3];
+                                if (sample_f32_fast<DEG7, false>(c7, cf, deg, t, E, f)) {    // pose2Octomap of getPose(t), certified
+                                    bool hit;
+                                    if (which == 0) hit = box_sweep_fast(g, A.sweep, Nc, f[0], f[1], f[2], &T, tile_words);
+                                    else {
+                                        // the three lattice counts of this pose (box_sweep's own expressions) pick the verdict
+                                        int idx = 0;
+#pragma unroll
+                                        for (int a = 0; a < 3; ++a) {
+                                            const double lo = f[a] - K.half[a], hi = f[a] + K.half[a];
+                                            if ((hi - lo) >= Nc.thr[a]) idx |= 1 << a;
+                                        }
+                                        hit = ((s_tt[(k - k_base) >> g_shift] >> idx) & 1) != 0;
                                     }
-                                    hit = ((s_tt[(k - k_base) >> q_shift] >> idx) & 1) != 0;
+                                    if (hit) {
+                                        if (k < my_first) my_first = k;
+                                        ++my_count;
+                                    }
+                                } else {
+                                    const int slot = atomicAdd(&q_n, 1);
+                                    if (slot < kQueueCap) q_idx[slot] = k;
                                 }
-                                if (hit) {
-                                    if (k < my_first) my_first = k;
-                                    ++my_count;
-                                }
-                            } else {
-                                const int slot = atomicAdd(&q_n, 1);
-                                if (slot < kQueueCap) q_idx[slot] = k;
                             }
                         }
                     }
@@ -1123,8 +1138,8 @@ int launch_corridor_check2(hipStream_t s, const GridView& g, int S, int deg, con
     A.coeffs = coeffs; A.n_samp = n_samp; A.delT = delT;
     A.sweep = SweepConst{{box[0], box[1], box[2]}, map_res, 1.0 / g.res};
     A.out_flag = out_flag; A.out_first = out_first; A.out_count = out_count;
-    // with the first pass' static LDS (12.9 KB): VIGO_CORRIDOR_WPS workgroups per CU (27 KB of tile for four)
-    const int tile_bytes = (160 * 1024 / VIGO_CORRIDOR_WPS - 13 * 1024) & ~255;
+    // with the first pass' static LDS (21.6 KB): VIGO_CORRIDOR_WPS workgroups per CU (18 KB of tile for four)
+    const int tile_bytes = (160 * 1024 / VIGO_CORRIDOR_WPS - 22 * 1024) & ~255;
     A.tile_words_cap = tile_bytes / 4;
     A.todo = todo;
     if (deg == 7) {
