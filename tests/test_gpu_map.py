@@ -180,6 +180,29 @@ def test_corridor_span_certificates_and_what_they_refuse(vigo_handle, box, map_r
     assert 0 < flag.mean() < 1
 
 
+def test_corridor_checker_on_more_segments_than_the_clock_workspace_holds(vigo_handle):
+    """Up to 16384 segments the sample-clock tables come from a kernel of their own (k_corridor_clocks, a thread per
+    segment); above that every workgroup writes its own: same results either way, and across the boundary"""
+    v = vigo_handle
+    w = maze_like_world()
+    set_world(v, w)
+    g, keep = ol.make_grid(w)
+    box = np.array([0.4, 0.4, 0.2])
+    S = 16400
+    coeffs, n_samp, delT, dur = synth.make_corridor_segments(61, S, extent_lo=(-4, -4, 0.6), extent_hi=(4, 4, 1.6), n_samples=40)
+    n_samp[::97] = 700
+    delT[::97] = dur[::97] / 700
+    dc, dn, dt = to_dev(coeffs, v.device), to_dev(n_samp, v.device), to_dev(delT, v.device)
+    big = [x.cpu().numpy() for x in v.corridor_check(dc, dn, dt, box, 0.2)]
+    small = [x.cpu().numpy() for x in v.corridor_check(dc[:16384], dn[:16384], dt[:16384], box, 0.2)]
+    for a, b in zip(big, small):
+        assert np.array_equal(a[:16384], b)
+    pick = np.sort(np.concatenate([np.arange(0, S, 97)[:60], np.random.default_rng(2).choice(S, 240, replace=False)]))
+    f_o, fi_o, cn_o = ol.corridor_check_batch(g, coeffs[pick], n_samp[pick], delT[pick], box, 0.2)
+    assert np.array_equal(f_o, big[0][pick]) and np.array_equal(fi_o, big[1][pick]) and np.array_equal(cn_o, big[2][pick])
+    assert 0 < big[0].mean() < 1
+
+
 def test_inflate_grid_matches_numpy_dilation(vigo_handle):
     """vigo_inflate_grid: bit0 = box dilation of bit2 (integer/byte work: bit-exact), other bits kept, in place"""
     v = vigo_handle

@@ -650,10 +650,15 @@ int vigo_corridor_check(vigo_handle_t h, int S, int deg, const double* coeffs, c
             return fail(h, VIGO_ERR_UNSUPPORTED, "corridor checker needs a grid origin that is a multiple of res (octomap keys)");
     }
     if (S == 0) return VIGO_OK;
-    int rc = ensure_scratch(h, (size_t)S * sizeof(int));      // the first pass' work list for the second
+    // scratch: the first pass' work list for the second, then (up to 16384 segments: 42 MB) the segments' clock tables
+    const size_t todo_bytes = ((size_t)S * sizeof(int) + 255) & ~(size_t)255;
+    const size_t clock_bytes = S <= 16384 ? vigo::corridor_clock_ws_bytes(S) : 0;
+    int rc = ensure_scratch(h, todo_bytes + clock_bytes);
     if (rc != VIGO_OK) return rc;
-    VIGO_HIP(h, (hipError_t)vigo::launch_corridor_check2(h->stream, h->grid, S, deg, coeffs, n_samp, delT, box, map_res,
-                                                         out_flag, out_first, out_count, static_cast<int*>(h->scratch)));
+    char* ws = static_cast<char*>(h->scratch);
+    VIGO_HIP(h, (hipError_t)vigo::launch_corridor_check2(h->stream, h->grid, S, deg, coeffs, n_samp, delT, box, map_res, out_flag,
+                                                         out_first, out_count, reinterpret_cast<int*>(ws),
+                                                         clock_bytes ? ws + todo_bytes : nullptr));
     return VIGO_OK;
 }
 

@@ -43,6 +43,7 @@ struct CorridorArgs {
     int32_t* out_count;
     int tile_words_cap;
     int* todo;           // per segment: 1 = left to the second pass (see k_corridor)
+    const ClockTable* clocks;   // per segment, written by k_corridor_clocks; NULL: every workgroup builds its own
     SweepConst sweep;
 };
 
@@ -474,6 +475,17 @@ constexpr int kBitWords = 2 * kBlock;  // a batch: up to kBlock spans of up to 6
 constexpr int kTtBytes = 16 * kBlock;  // the smallest pieces are a sixteenth of a span
 constexpr int kParallelMax = 2 * kBlock;
 
+// The clock tables of all segments, a thread each: the table is thread-serial work (~9 us), which a workgroup of
+// k_corridor would otherwise wait for with 255 lanes idle.
+__global__ void __launch_bounds__(64) k_corridor_clocks(int S, const int32_t* __restrict__ n_samp, const double* __restrict__ delT,
+                                                        ClockTable* __restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    out[s].n = -1;
+    const int n = n_samp[s];
+    if (n > 0) (void)build_clock_table(delT[s], n - 1, out[s]);
+}
+
 // Two passes, one launch each (PASS 0 then PASS 1), so that neither carries the other's registers:
 //   PASS 0  segments of more than 512 samples by certified spans, shorter ones a sample per lane (both need the clock
 //           table).  A segment it cannot take — degenerate delT, a box of more than 3 map cells per axis, non-finite
@@ -524,14 +536,21 @@ __global__ void __launch_bounds__(kBlock, VIGO_CORRIDOR_WPS) k_corridor(GridView
     const int n_chunks = (n + kChunk - 1) / kChunk;
 
     // ---- per-segment constants, spread over the block ----
-    //   clock   one lane of wave 3 writes the sample clock down as a table (vigo_exact_time.hpp);
+    //   clock   the sample clock as a table (vigo_exact_time.hpp): copied from k_corridor_clocks' output, or written down
+    //           here by one lane of wave 3 (a launch of more segments than the workspace is made for);
     //   bounds  the Bernstein coefficients of the segment and of its derivative over [0, Tu], one per thread of waves 0
     //           and 1 (convex-hull property: min b_i <= p(t) <= max b_i), Tu >= every clock value — the accumulated
     //           clock stays within n u of k delT, u = 2^-53.  The position bound only sizes the LDS tile: a pose whose
     //           lattice points fall outside the tile takes the L2 path in box_sweep, so results never depend on it.  The
     //           derivative bound is the Lipschitz constant of the span certificates (SpanConst).
     const double Tu = n > 0 ? (double)(n - 1) * dT * (1.0 + 0x1p-20) : 0.0;
-    if (tid == 3 * 64 && n > 0) (void)build_clock_table(dT, n - 1, s_clock);
+    if (A.clocks) {
+        const int* src = reinterpret_cast<const int*>(A.clocks + s);
+        int* dst = reinterpret_cast<int*>(&s_clock);
+        for (int i = tid; i < (int)(sizeof(ClockTable) / sizeof(int)); i += kBlock) dst[i] = src[i];
+    } else if (tid == 3 * 64 && n > 0) {
+        (void)build_clock_table(dT, n - 1, s_clock);
+    }
     if (tid < 3 * (deg + 1)) {
         const int a = tid / (deg + 1), i = tid % (deg + 1);
         const double* c = cf + a * (kMaxDeg + 1);
@@ -1121,6 +1140,8 @@ __global__ void k_esdf_brick(int nx, int ny, int nz, int nby, int nbz, size_t to
 
 }  // namespace
 
+size_t corridor_clock_ws_bytes(int S) { return (size_t)S * sizeof(ClockTable); }
+
 int launch_esdf_brick(hipStream_t s, int nx, int ny, int nz, const float* src, float* dst) {
     const size_t total = esdf_bricked_floats(nx, ny, nz);
     const int block = 256;
@@ -1131,7 +1152,7 @@ int launch_esdf_brick(hipStream_t s, int nx, int ny, int nz, const float* src, f
 
 int launch_corridor_check2(hipStream_t s, const GridView& g, int S, int deg, const double* coeffs,
                           const int32_t* n_samp, const double* delT, const double box[3],
-                          double map_res, uint8_t* out_flag, int32_t* out_first, int32_t* out_count, int* todo) {
+                          double map_res, uint8_t* out_flag, int32_t* out_first, int32_t* out_count, int* todo, void* clock_ws) {
     if (S <= 0) return hipSuccess;
     CorridorArgs A{};
     A.S = S; A.deg = deg;
@@ -1142,6 +1163,9 @@ int launch_corridor_check2(hipStream_t s, const GridView& g, int S, int deg, con
     const int tile_bytes = (160 * 1024 / VIGO_CORRIDOR_WPS - 22 * 1024) & ~255;
     A.tile_words_cap = tile_bytes / 4;
     A.todo = todo;
+    A.clocks = static_cast<const ClockTable*>(clock_ws);
+    if (clock_ws)
+        hipLaunchKernelGGL(k_corridor_clocks, dim3((S + 63) / 64), dim3(64), 0, s, S, n_samp, delT, static_cast<ClockTable*>(clock_ws));
     if (deg == 7) {
         hipLaunchKernelGGL((k_corridor<0, true>), dim3(S), dim3(kBlock), tile_bytes, s, g, A);
         hipLaunchKernelGGL((k_corridor<1, true>), dim3(S), dim3(kBlock), tile_bytes, s, g, A);

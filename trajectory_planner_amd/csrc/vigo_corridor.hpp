@@ -7,9 +7,11 @@
 
 namespace vigo {
 
-// todo: S ints of device scratch (which segments the first pass left to the second)
+// todo: S ints of device scratch (which segments the first pass left to the second); clock_ws: corridor_clock_ws_bytes(S)
+// bytes of device scratch, 8-byte aligned, for the segments' sample-clock tables, or NULL (every workgroup then builds its own)
+size_t corridor_clock_ws_bytes(int S);
 int launch_corridor_check2(hipStream_t s, const GridView& g, int S, int deg, const double* coeffs, const int32_t* n_samp,
                            const double* delT, const double box[3], double map_res, uint8_t* out_flag, int32_t* out_first,
-                           int32_t* out_count, int* todo);
+                           int32_t* out_count, int* todo, void* clock_ws);
 
 }  // namespace vigo
