@@ -8,10 +8,16 @@
 //   stage   the voxels that box (+ the collision box + 1 voxel) can touch are copied from the
 //           packed HBM planes into an LDS tile as ONE bit per voxel (unknown | occupied — both
 //           mean "collides" for the sweep, PO.cpp:580-588);
-//   sweep   every thread walks chunks of 16 consecutive samples (the chunk's first clock value
-//           comes from accumulated_time(), the rest by the reference's own t += delT) and looks
-//           every lattice point of the box sweep up in the LDS tile (a segment makes ~10^5
-//           lookups inside a few thousand words).
+//   decide  spans of 64 / 32 / 16 consecutive samples by ONE evaluation each where that provably gives every sample's
+//           verdict (an interval that holds all their float positions, pushed through the reference's own monotone
+//           expressions at both ends: same voxel keys at both ends = same keys for every sample), spans that cannot be
+//           decided cut in four, twice; what is left goes through the per-sample sweep, compacted so that every lane
+//           has a sample (SpanConst, k_corridor PASS 0).  The sample clock t += delT comes from a per-segment table
+//           (vigo_exact_time.hpp);
+//   walk    segments the certificates do not apply to (degenerate clocks, boxes of more than 3 map cells per axis,
+//           non-finite coefficients, samples further apart than 1/32 of a voxel) take the walk of rounds 1-2: every
+//           thread over chunks of 16 consecutive samples, every lattice point of the box looked up in the tile
+//           (k_corridor PASS 1).
 // A tile too large for the LDS budget falls back to lookups in the packed planes (L2).
 #include <type_traits>
 
