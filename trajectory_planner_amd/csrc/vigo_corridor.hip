@@ -792,6 +792,7 @@ __global__ void __launch_bounds__(kBlock, VIGO_CORRIDOR_WPS) k_corridor(GridView
                 for (int phase = 0; phase < 3; ++phase) {
                     const int cnt = phase == 0 ? min(per_batch, n_spans - base) : min(s_in[(phase - 1) & 1], kItemCap);
                     const int child = (S1 >> 2) >> (2 * phase);             // a quarter of this round's pieces
+                    // (consecutive pieces on consecutive waves instead of consecutive lanes: measured 2 % slower)
                     for (int i = tid; i < cnt; i += kBlock) {
                         int k0, len;
                         if (phase == 0) {
