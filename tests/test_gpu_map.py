@@ -171,6 +171,7 @@ def test_corridor_span_certificates_and_what_they_refuse(vigo_handle, box, map_r
     delT[15], delT[16], delT[17] = 0.0, -delT[16], delT[17] * 1e-9
     n_samp[15:17] = 2500
     coeffs[18, :, 1:] = 0.0                                # a segment that does not move
+    coeffs[19, 0, 0], coeffs[20, 1, 0], coeffs[21, 2, 0] = 1e39, -3.4028234e38, 1e20   # finite doubles beyond / at / far below the floats' range
     flag, first, count = (x.cpu().numpy() for x in v.corridor_check(to_dev(coeffs, v.device), to_dev(n_samp, v.device), to_dev(delT, v.device), box, map_res))
     for s in range(len(coeffs)):
         fi, cn = C.c_int(), C.c_int()

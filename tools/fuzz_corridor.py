@@ -57,7 +57,7 @@ for case in range(cases):
     coeffs[11, 1, 0] = -half + 0.05
     coeffs[11, 1, 1] = -abs(coeffs[11, 1, 1])
     if rng.random() < 0.5:
-        coeffs[12, int(rng.integers(0, 3)), int(rng.integers(0, deg + 1))] = float(rng.choice([np.nan, np.inf, -np.inf, 1e300]))
+        coeffs[12, int(rng.integers(0, 3)), int(rng.integers(0, deg + 1))] = float(rng.choice([np.nan, np.inf, -np.inf, 1e300, 1e39, -4e38, 1e20, 3.4028234e38]))
     delT[13] = 0.0
     delT[14] = -delT[14]
     delT[15] = delT[15] * 1e-9

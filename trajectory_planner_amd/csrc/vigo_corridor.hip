@@ -467,7 +467,14 @@ __device__ __forceinline__ int certify_span(const GridView& g, const SweepConst&
     axis_span(K.half[0], flo[0], fhi[0], K.N.nlo[0], K.N.nhi[0], C.map_res, C.rf, g.bmin[0], g.bmax[0], g.key0[0], g.nx, kx, constant, out);
     axis_span(K.half[1], flo[1], fhi[1], K.N.nlo[1], K.N.nhi[1], C.map_res, C.rf, g.bmin[1], g.bmax[1], g.key0[1], g.ny, ky, constant, out);
     axis_span(K.half[2], flo[2], fhi[2], K.N.nlo[2], K.N.nhi[2], C.map_res, C.rf, g.bmin[2], g.bmax[2], g.key0[2], g.nz, kz, constant, out);
-    if (out) return 2;
+    if (out) {
+        // ... provided every float of the span is finite: a pose at infinity on ANY axis has no lattice at all (see
+        // box_sweep) and does not collide, whatever this axis says.  (`constant` implies it: the bounds tests passed.)
+        bool finite = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) finite = finite && fabsf(flo[a]) <= 3.402823466e38f && fabsf(fhi[a]) <= 3.402823466e38f;   // false for NaN
+        return finite ? 2 : 0;
+    }
     if (!constant) return 0;
     const unsigned tt = lattice_any_all(g, T, tile_words, kx, ky, kz, K.N);
     if (tt == 0u) return 1;
