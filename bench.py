@@ -478,6 +478,37 @@ def main():
                 del pw, pb
             except (RuntimeError, OSError) as e:      # the host facade library is not built: say so, do not invent numbers
                 extra["config2_pipeline_guides"] = {"error": str(e)}
+            # (e3) BASELINE configs[2]: the min-snap corridor checker, 4096 segments x 10 000 samples on a 256 x 256 x 64 world
+            #      (tools/time_corridor.py's input; parity at this size: tests/test_gpu_fullsize.py).  Never `value`.
+            try:
+                rng3 = np.random.default_rng(3)
+                vox3 = np.zeros((256, 256, 64), dtype=np.uint8)
+                for _ in range(300):
+                    c3 = rng3.integers(8, 248, size=2); s3 = rng3.integers(1, 6, size=2)
+                    vox3[c3[0] - s3[0]:c3[0] + s3[0], c3[1] - s3[1]:c3[1] + s3[1], 0:rng3.integers(10, 64)] |= 4
+                unk3 = rng3.random((32, 32, 8)) < 0.05
+                vox3[np.repeat(np.repeat(np.repeat(unk3, 8, 0), 8, 1), 8, 2)] |= 2
+                v3 = Vigo(local_rank, P, prec_code[args.precision])
+                v3.use_current_stream()
+                v3.set_grid(T(vox3), np.array([-12.8, -12.8, -1.0]), 0.1)
+                co3, ns3, dl3, _ = synth.make_corridor_segments(33, 4096, extent_lo=(-10, -10, 0.5), extent_hi=(10, 10, 2.5), n_samples=10000)
+                dco, dns, ddl = T(co3), T(ns3), T(dl3)
+                for _ in range(3):
+                    fl3, _, _ = v3.corridor_check(dco, dns, ddl, [0.4, 0.4, 0.2], 0.2)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                for _ in range(20):
+                    fl3, _, _ = v3.corridor_check(dco, dns, ddl, [0.4, 0.4, 0.2], 0.2)
+                torch.cuda.synchronize()
+                d3 = (time.perf_counter() - t3) / 20
+                extra["config3_corridor"] = {"workload": "configs[2]: 4096 min-snap segments x 10 000 samples, box 0.4 / 0.4 / 0.2, map_resolution 0.2, 256 x 256 x 64 voxels",
+                                             "ms": d3 * 1e3, "value": 4096e4 / d3, "unit": "samples/s", "colliding_segments": int(fl3.sum().item()),
+                                             "note": "three launches per call (per-segment clock tables, certified spans, the walk for what they refuse); "
+                                                     "counters: profiles/r03_pmc_corridor_pass0.json; never `value`"}
+                v3.close()
+                del vox3, dco
+            except (RuntimeError, OSError) as e:
+                extra["config3_corridor"] = {"error": str(e)}
     # (f) one GPU's shard of BASELINE configs[3] (8192 x 64 control points, 512^3 map) on every rank count, so the
     #     1 -> 8 record covers the configuration BASELINE names for 8 GPUs; never `value`
     if args.workload == "config2" and not args.no_extras:
