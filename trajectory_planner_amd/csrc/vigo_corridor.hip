@@ -675,12 +675,12 @@ __global__ void __launch_bounds__(kBlock, VIGO_CORRIDOR_WPS) k_corridor(GridView
         if (T.in_lds) {
             const uint32_t* unk = g.planes + g.plane_words;
             const uint32_t* occ = g.planes + 2 * g.plane_words;
-            for (int w = tid; w < (int)words; w += kBlock) {
-                const int lw = w % T.tw;
-                const int ly = (w / T.tw) % T.ty;
-                const int lx = w / (T.tw * T.ty);
-                const size_t gw = ((size_t)(T.x0 + lx) * g.ny + (T.y0 + ly)) * g.nzw + (T.w0 + lw);
-                tile_words[w] = unk[gw] | occ[gw];
+            // a thread per (x, y) column, its z words in turn: one integer division per column instead of three per word
+            const int cols = T.tx * T.ty;
+            for (int col = tid; col < cols; col += kBlock) {
+                const int lx = col / T.ty, ly = col - lx * T.ty;
+                const size_t gw = ((size_t)(T.x0 + lx) * g.ny + (T.y0 + ly)) * g.nzw + T.w0;
+                for (int lw = 0; lw < T.tw; ++lw) tile_words[col * T.tw + lw] = unk[gw + lw] | occ[gw + lw];
             }
         }
     }
@@ -688,8 +688,8 @@ __global__ void __launch_bounds__(kBlock, VIGO_CORRIDOR_WPS) k_corridor(GridView
 
     // ---- how the samples are visited (block-uniform) ----
     // PASS 0 takes a segment when it has a clock table and its lattice counts go by compare (CountConst):
-    //   certify  n > 512 and samples closer than 1/32 of a voxel: certified spans of 32 or 16 samples, cut in four
-    //            where the certificate fails (see SpanConst);
+    //   certify  n > 512 and samples closer than 1/32 of a voxel: certified spans of 64, 32 or 16 samples (the largest whose
+    //            reach stays within a quarter of a voxel), cut in four where the certificate fails (see SpanConst);
     //   else     n <= 512: every sample through the per-sample path, a lane each.
     // Everything else — degenerate delT, a box of more than 3 map cells per axis, non-finite coefficients, fast or very
     // long segments, an exact-power queue that overflows — is PASS 1's: the walk of rounds 1-2, every thread over chunks
