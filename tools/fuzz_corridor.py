@@ -62,6 +62,17 @@ for case in range(cases):
     delT[14] = -delT[14]
     delT[15] = delT[15] * 1e-9
     n_samp[13:15] = np.minimum(n_samp[13:15], 3000)         # (the oracle and the device walk these clocks step by step)
+    # boundary huggers: a lattice point of the box rides a voxel face (or the metric bound) while the pose creeps by
+    # micrometres, so that the rounding of the float position alone decides keys and counts from sample to sample
+    for sgm in range(16, 22):
+        a = int(rng.integers(0, 3))
+        face = origin[a] + res * float(rng.integers(2, vox.shape[a] - 2))
+        off = float(rng.choice([-1.0, 0.0, 1.0])) * box[a] / 2 + float(rng.choice([0.0, map_res, 2 * map_res]))
+        coeffs[sgm, a, :] = 0.0
+        coeffs[sgm, a, 0] = face - off + float(rng.choice([0.0, 1e-7, -1e-7, 3e-6, -3e-6]))
+        coeffs[sgm, a, 1] = float(rng.choice([0.0, 1e-6, -1e-6, 2e-5, -2e-5, 1e-3]))
+        if rng.random() < 0.5:
+            coeffs[sgm, :, 2:] *= 0.01                       # and slow elsewhere: long certified spans around the flicker
     flag, first, count = (x.cpu().numpy() for x in v.corridor_check(to_dev(coeffs, v.device), to_dev(n_samp, v.device), to_dev(delT, v.device), box, map_res))
     ok = True
     for s in range(S):
