@@ -1,6 +1,8 @@
 // vigo_corridor.hpp — launcher of the corridor checker's two passes (vigo_corridor.hip, k_corridor).
 // Supersedes launch_corridor_check() as declared in vigo_internal.hpp: that declaration has no work list and is left
 // there only because vigo_internal.hpp is part of the solve kernels' build id (profiles/pmc_*.json are tied to it).
+// For the same reason this header is not in the Makefile's HDRS list (the Makefile is part of that id too): the two files
+// that include it are vigo_corridor.hip and vigo_api.cpp — touch them, or `make clean`, after editing it.
 #pragma once
 
 #include "vigo_internal.hpp"
