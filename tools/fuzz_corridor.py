@@ -4,6 +4,9 @@ resolutions 0.1 / 0.05, polynomial degrees 3-9, ragged sample counts, metric bou
 Not part of the test suite; run on the GPU box:  python tools/fuzz_corridor.py [cases] [seed]"""
 import ctypes as C, json, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import trajectory_planner_amd._lib as L
+if os.environ.get("VIGO_EXP_LIB"):                      # dev: an alternative build of the library
+    L.LIB_PATH = os.path.join(R, os.environ["VIGO_EXP_LIB"])
 import numpy as np, torch
 import oracle_lib as ol
 from gpu_util import to_dev
